@@ -1,0 +1,436 @@
+"""Generate tests/golden/*.pt by running the REFERENCE itself (build container only).
+
+    python tests/golden/make_golden.py
+
+/root/reference is imported read-only as the package `models.vae` (its own absolute imports
+need that name).  Two of its dependencies are absent from the image (`helpers`, `tree`); they
+are registered as in-memory modules holding only the trivial utilities the hot path calls
+(zeros_like / ones_like / same_type / eps / nan_check_and_break, a Linear for the Sequential
+projection).  Nothing from the reference is copied: the fixtures are inputs, the injected
+noise, and the outputs the reference computed (data only).  The NLL lives in the absent
+`helpers.distributions` and is therefore NOT in any fixture (parity unpinned, see
+oracle/cpu_ref.py).
+
+The GPU box has no /root/reference; only the .pt files travel.
+"""
+import os
+import sys
+import types
+import importlib.util
+
+import torch
+import torch.nn as nn
+import torch.distributions as D
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference'
+EPS_TOL = 1e-6  # helpers.utils.eps(half=False): value assumed, helpers is un-vendored
+
+
+def install_reference():
+    D.Distribution.set_default_validate_args(False)  # the reference predates validation-by-default
+
+    helpers = types.ModuleType('helpers')
+    utils = types.ModuleType('helpers.utils')
+    layers = types.ModuleType('helpers.layers')
+    dists = types.ModuleType('helpers.distributions')
+    tree = types.ModuleType('tree')
+
+    utils.zeros_like = torch.zeros_like
+    utils.ones_like = torch.ones_like
+    utils.eps = lambda half=False: 1e-4 if half else EPS_TOL
+    utils.nan_check_and_break = lambda t, name='': None
+    utils.float_type = lambda cuda: torch.FloatTensor
+    utils.long_type = lambda cuda: torch.LongTensor
+    utils.same_type = lambda half, cuda: torch.HalfTensor if half else torch.FloatTensor
+    utils.add_noise_to_imgs = lambda x: x
+    utils.number_of_parameters = lambda m: sum(p.numel() for p in m.parameters())
+    utils.one_hot_np = None
+
+    def get_encoder(name='dense', **config):
+        in_size = config['input_shape'][0]
+        return lambda output_size: nn.Linear(in_size, output_size)
+
+    layers.get_encoder = get_encoder
+    layers.get_decoder = get_encoder
+    layers.str_to_activ_module = lambda s: {'tanh': nn.Tanh, 'relu': nn.ReLU}[s]
+
+    class EMA(nn.Module):
+        def __init__(self, decay=0.999):
+            super().__init__()
+
+        def forward(self, x):
+            return x
+
+    layers.EMA = EMA
+    for n in ('flatten_layers', 'LinearWarmupWithCosineAnnealing', 'GatedDense', 'SineLinear', 'SNLinear',
+              'BasicDenseBlock', 'Identity', 'View'):
+        setattr(layers, n, None)
+
+    def _absent(*a, **k):
+        raise RuntimeError('helpers.distributions is un-vendored: NLL is not part of any fixture')
+
+    dists.nll = _absent
+    dists.nll_activation = _absent
+    dists.nll_has_variance = lambda s: False
+    tree.map_structure = lambda f, *s: f(*s)
+
+    helpers.utils, helpers.layers, helpers.distributions = utils, layers, dists
+    sys.modules.update({'helpers': helpers, 'helpers.utils': utils, 'helpers.layers': layers,
+                        'helpers.distributions': dists, 'tree': tree})
+
+    models = types.ModuleType('models')
+    models.__path__ = []
+    sys.modules['models'] = models
+    spec = importlib.util.spec_from_file_location('models.vae', os.path.join(REF, '__init__.py'),
+                                                  submodule_search_locations=[REF])
+    vae = importlib.util.module_from_spec(spec)
+    sys.modules['models.vae'] = vae
+    spec.loader.exec_module(vae)
+    models.vae = vae
+    return vae
+
+
+def detach_tree(o):
+    if torch.is_tensor(o):
+        return o.detach().clone()
+    if isinstance(o, dict):
+        return {k: detach_tree(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [detach_tree(v) for v in o]
+    if hasattr(o, 'item'):  # numpy scalar (tau after annealing)
+        return float(o)
+    return o
+
+
+def grads_of(z, kl, logits, w):
+    (g,) = torch.autograd.grad((z * w).sum() + kl.sum(), logits, allow_unused=True)
+    return None if g is None else g.detach().clone()
+
+
+def base_config(**kw):
+    c = {'continuous_size': 8, 'discrete_size': 5, 'half': False, 'cuda': False, 'epochs': 10,
+         'continuous_mut_info': 0, 'discrete_mut_info': 0, 'kl_beta': 1.0, 'use_prior_kl': False,
+         'flow_type': 'maf', 'latent_size': 16, 'memory_read_steps': 1, 'reparam_type': 'isotropic_gaussian'}
+    c.update(kw)
+    return c
+
+
+def make_gaussian(vae, out):
+    R = vae.reparameterizers
+    for L in (4, 32):
+        for train in (True, False):
+            torch.manual_seed(100 + L)
+            B = 8
+            logits = torch.randn(B, 2 * L, requires_grad=True)
+            prior_logits = torch.randn(B, 2 * L)
+            w = torch.randn(B, L)
+            m = R.IsotropicGaussian(base_config(continuous_size=2 * L))
+            m.train(train)
+            torch.manual_seed(7)
+            noise = torch.zeros(B, L).normal_()
+            torch.manual_seed(7)
+            z, params = m(logits)
+            kl = m.kl(params)
+            # a second parameter set as the prior (VRNN / class-conditioned use): sigma made positive
+            pl = torch.cat([prior_logits[:, :L], torch.sigmoid(prior_logits[:, L:])], -1).requires_grad_(True)
+            _, pparams = m(pl)
+            klp = m.kl(params, pparams)
+            g = grads_of(z, kl, logits, w)
+            gp_q, gp_p = torch.autograd.grad(klp.sum(), [logits, pl])
+            out['gauss_L%d_%s' % (L, 'train' if train else 'eval')] = detach_tree({
+                'logits': logits, 'noise': noise, 'w': w, 'z': z, 'params': params, 'kl': kl,
+                'prior_logits': pl, 'prior_params': pparams, 'kl_prior': klp, 'grad_logits': g,
+                'grad_klp_logits': gp_q, 'grad_klp_prior_logits': gp_p, 'training': train, 'eps_tol': EPS_TOL})
+    # 3-D logits [B, T, 2L] (slice -1, kl [B, T])
+    torch.manual_seed(5)
+    logits = torch.randn(4, 3, 16)
+    m = R.IsotropicGaussian(base_config(continuous_size=16))
+    torch.manual_seed(9)
+    noise = torch.zeros(4, 3, 8).normal_()
+    torch.manual_seed(9)
+    z, params = m(logits)
+    out['gauss_3d'] = detach_tree({'logits': logits, 'noise': noise, 'z': z, 'params': params, 'kl': m.kl(params)})
+
+
+def make_gumbel(vae, out):
+    R = vae.reparameterizers
+    for K in (5, 32):
+        for train in (True, False):
+            for tau in (1.0, 0.5):
+                torch.manual_seed(200 + K)
+                B = 8
+                logits = torch.randn(B, K)
+                # rows 0/1: exact ties after noise are forced below through U; rows 2/3: near ties
+                logits = logits.requires_grad_(True)
+                prior_logits = torch.randn(B, K, requires_grad=True)
+                w = torch.randn(B, K)
+                m = R.GumbelSoftmax(base_config(discrete_size=K))
+                m.train(train)
+                m.tau = tau
+                torch.manual_seed(11)
+                U = torch.rand(B, K)
+                torch.manual_seed(11)
+                z, params = m(logits)
+                kl0 = m.kl(params)
+                _, pparams = m(prior_logits)
+                klp = m.kl(params, pparams)
+                g, gprior = torch.autograd.grad((z * w).sum() + klp.sum(), [logits, prior_logits])
+                hard = params['discrete']['z_hard'].detach()
+                out['gumbel_K%d_%s_tau%g' % (K, 'train' if train else 'eval', tau)] = detach_tree({
+                    'logits': logits, 'U': U, 'w': w, 'tau': tau, 'z': z, 'params': params, 'kl_none': kl0,
+                    'prior_logits': prior_logits, 'prior_log_q_z': pparams['discrete']['log_q_z'],
+                    'kl_prior': klp, 'grad_logits': g, 'grad_prior_logits': gprior,
+                    'hard_index': hard.argmax(-1), 'hard_count': (hard == 1).sum(-1), 'training': train})
+    # exact ties: identical logits and identical U in several columns -> multi-hot z_hard
+    torch.manual_seed(3)
+    K = 8
+    logits = torch.randn(6, K)
+    logits[:, 5] = logits[:, 2]
+    logits[0, 7] = logits[0, 2]
+    big = logits.max() + 3.0
+    logits[:, 2] = big
+    logits[:, 5] = big
+    logits[0, 7] = big
+    m = R.GumbelSoftmax(base_config(discrete_size=K))
+    m.train(False)
+
+    class FixedRand(object):
+        """Make torch.rand return a chosen draw for one call (noise injection without touching the reference)."""
+
+        def __init__(self, U):
+            self.U, self.orig = U, torch.rand
+
+        def __enter__(self):
+            torch.rand = lambda *a, **k: self.U.clone()
+
+        def __exit__(self, *a):
+            torch.rand = self.orig
+
+    U = torch.rand(6, K)
+    U[:, 5] = U[:, 2]
+    U[0, 7] = U[0, 2]
+    with FixedRand(U):
+        z, params = m(logits)
+    hard = params['discrete']['z_hard']
+    assert int((hard == 1).sum(-1).max()) >= 2
+    out['gumbel_ties'] = detach_tree({'logits': logits, 'U': U, 'tau': 1.0, 'z': z, 'params': params,
+                                      'hard_count': (hard == 1).sum(-1), 'training': False})
+    # annealing: iteration / tau evolution over 25 training forwards (gumbel.py:91-108, :334)
+    m = R.GumbelSoftmax(base_config(discrete_size=4))
+    m.train(True)
+    m.iteration = 99990
+    taus = []
+    for _ in range(25):
+        m(torch.zeros(2, 4))
+        taus.append(float(m.tau))
+    out['gumbel_anneal'] = {'start_iteration': 99990, 'taus': taus, 'end_iteration': m.iteration}
+
+
+def make_bernoulli(vae, out):
+    R = vae.reparameterizers
+    for K in (5, 32):
+        for train in (True, False):
+            for tau in (1.0, 0.3):
+                torch.manual_seed(300 + K)
+                B = 8
+                logits = (torch.randn(B, K) * 2).requires_grad_(True)
+                prior_logits = torch.randn(B, K, requires_grad=True)
+                w = torch.randn(B, K)
+                m = R.Bernoulli(base_config(discrete_size=K))
+                m.train(train)
+                m.tau = tau
+                torch.manual_seed(13)
+                U = torch.rand(B, K)
+                torch.manual_seed(13)
+                z, params = m(logits)
+                kl0 = m.kl(params)
+                klp = m.kl(params, {'discrete': {'logits': prior_logits}})
+                g = grads_of(z, kl0, logits, w)
+                gq, gp = torch.autograd.grad(klp.sum(), [logits, prior_logits])
+                out['bern_K%d_%s_tau%g' % (K, 'train' if train else 'eval', tau)] = detach_tree({
+                    'logits': logits, 'U': U, 'w': w, 'tau': tau, 'z': z, 'params': params, 'kl_none': kl0,
+                    'prior_logits': prior_logits, 'kl_prior': klp, 'grad_logits': g,
+                    'grad_klp_logits': gq, 'grad_klp_prior_logits': gp, 'training': train})
+
+
+def make_beta(vae, out):
+    R = vae.reparameterizers
+    for L in (4, 32):
+        torch.manual_seed(400 + L)
+        B = 8
+        logits = (torch.randn(B, 2 * L) * 2).requires_grad_(True)
+        prior_logits = torch.randn(B, 2 * L, requires_grad=True)
+        m = R.Beta(base_config(continuous_size=2 * L))
+        m.train(True)
+        z, params = m(logits)
+        _, pparams = m(prior_logits)
+        kl0 = m.kl(params)
+        klp = m.kl(params, pparams)
+        ll = m.log_likelihood(z.detach(), params)
+        (g0,) = torch.autograd.grad(kl0.sum() + params['beta']['conc1_mean'] + 2 * params['beta']['conc2_mean'],
+                                    logits, retain_graph=True)
+        gq, gp = torch.autograd.grad(klp.sum(), [logits, prior_logits])
+        out['beta_L%d' % L] = detach_tree({
+            'logits': logits, 'z_drawn': z, 'params': params, 'kl_none': kl0, 'prior_logits': prior_logits,
+            'kl_prior': klp, 'log_likelihood': ll, 'grad_kl0_means_logits': g0, 'grad_klp_logits': gq,
+            'grad_klp_prior_logits': gp})
+
+
+def make_flow_kl(vae, out):
+    R = vae.reparameterizers
+    torch.manual_seed(500)
+    m = R.FlowReparameterizer(base_config(continuous_size=6, latent_size=16))
+    # 2-D: logdet [B,1] -> the [B,B] broadcast of SURVEY Q6
+    u = torch.randn(8, 6, requires_grad=True)
+    logdet = torch.randn(8, 1, requires_grad=True)
+    kl = m.kl({'recon_x': u, 'logdet': logdet})
+    gu, gl = torch.autograd.grad((kl * torch.arange(1., 9.)).sum(), [u, logdet])
+    out['flowkl_2d'] = detach_tree({'u': u, 'logdet': logdet, 'kl': kl, 'w': torch.arange(1., 9.),
+                                    'grad_u': gu, 'grad_logdet': gl})
+    # 3-D: logdet [B,R]
+    u = torch.randn(4, 3, 6, requires_grad=True)
+    logdet = torch.randn(4, 3, requires_grad=True)
+    kl = m.kl({'recon_x': u, 'logdet': logdet})
+    gu, gl = torch.autograd.grad((kl * torch.arange(1., 5.)).sum(), [u, logdet])
+    out['flowkl_3d'] = detach_tree({'u': u, 'logdet': logdet, 'kl': kl, 'w': torch.arange(1., 5.),
+                                    'grad_u': gu, 'grad_logdet': gl})
+    # the full module forward through the real MAF flow (weights saved) for the Sequential drop-in test
+    m.eval()
+    x = torch.randn(8, 6)
+    f, p = m(x)
+    out['flow_forward'] = detach_tree({'x': x, 'flow': f, 'logdet': p['logdet'], 'kl': m.kl(p),
+                                       'state_dict': {k: v for k, v in m.state_dict().items()}})
+
+
+def make_concat(vae, out):
+    R = vae.reparameterizers
+    for train in (True, False):
+        torch.manual_seed(600)
+        B, L, K = 8, 4, 5
+        cfg = base_config(continuous_size=2 * L, discrete_size=K)
+        m = R.ConcatReparameterizer(['isotropic_gaussian', 'discrete'], cfg)
+        m.train(train)
+        logits = torch.randn(B, 2 * L + K, requires_grad=True)
+        w = torch.randn(B, L + K)
+        torch.manual_seed(17)
+        noise = torch.zeros(B, L).normal_() if train else None
+        U = torch.rand(B, K)
+        torch.manual_seed(17)
+        z, params = m(logits)
+        kl = m.kl(params)
+        g = grads_of(z, kl, logits, w)
+        out['concat_%s' % ('train' if train else 'eval')] = detach_tree({
+            'logits': logits, 'noise': noise, 'U': U, 'w': w, 'z': z, 'params': params, 'kl': kl,
+            'grad_logits': g, 'input_size': m.input_size, 'output_size': m.output_size, 'training': train,
+            'scalars': m.get_reparameterizer_scalars()})
+
+
+def make_sequential(vae, out):
+    R = vae.reparameterizers
+    torch.manual_seed(700)
+    B, L, Fdim = 8, 4, 6
+    cfg = base_config(continuous_size=2 * L, latent_size=16)
+    # Gaussian -> Flow: the flow reads config['continuous_size'] too, so the reference's own config
+    # couples F to 2L; use F = 2L = 8
+    m = R.SequentialReparameterizer(['isotropic_gaussian', 'flow'], cfg)
+    m.train(True)
+    logits = torch.randn(B, 2 * L, requires_grad=True)
+    torch.manual_seed(19)
+    noise = torch.zeros(B, L).normal_()
+    torch.manual_seed(19)
+    z, params = m(logits)
+    kl = m.kl(params)
+    (g,) = torch.autograd.grad(z.sum() + kl.sum(), logits)
+    out['sequential_gauss_flow'] = detach_tree({
+        'logits': logits, 'noise': noise, 'z': z, 'params': params, 'kl': kl, 'grad_logits': g,
+        'input_size': m.input_size, 'output_size': m.output_size,
+        'state_dict': {k: v for k, v in m.state_dict().items()}})
+
+
+def make_elbo(vae, out):
+    """AbstractVAE.loss_function called unbound on a stub: pins the combine (abstract_vae.py:356-388)."""
+    AV = vae.abstract_vae.AbstractVAE if hasattr(vae, 'abstract_vae') else sys.modules['models.vae.abstract_vae'].AbstractVAE
+    torch.manual_seed(800)
+    B = 16
+    nll = torch.rand(B) * 100
+    kld = torch.rand(B) * 10
+    extra = {'a': torch.rand(B), 'b': torch.rand(B)}
+    for beta, with_extra in ((1.0, False), (0.25, True)):
+        class Stub(object):
+            training = False
+            config = {'nll_type': 'bernoulli', 'kl_beta': beta, 'half': True, 'cuda': False}
+            kl_annealer = None
+            nll = lambda self, x, r, t: nll  # noqa: E731
+            kld = lambda self, p: kld  # noqa: E731
+            mut_info = lambda self, p, b: torch.zeros(b)  # noqa: E731
+            compute_kl_beta = AV.compute_kl_beta
+        res = AV.loss_function(Stub(), None, torch.zeros(B, 1), {}, **(extra if with_extra else {}))
+        out['elbo_beta%g_%s' % (beta, 'extra' if with_extra else 'plain')] = detach_tree({
+            'nll': nll, 'kld': kld, 'extra': extra if with_extra else {}, 'kl_beta': beta, 'result': res})
+
+
+def make_vrnn(vae, out):
+    """VRNN.reparameterize / kld / _add_loss_map / _mean_map on stubs (vrnn.py:395-447, :723-829)."""
+    V = sys.modules['models.vae.vrnn'].VRNN
+    R = vae.reparameterizers
+    torch.manual_seed(900)
+    B, L, T = 8, 4, 4
+    cfg = base_config(continuous_size=2 * L, reparam_type='isotropic_gaussian')
+    rep = R.IsotropicGaussian(cfg)
+    rep.train(True)
+
+    class Stub(object):
+        config = cfg
+        reparameterizer = rep
+        _clamp_variance = V._clamp_variance
+        kld = V.kld
+    steps, losses = [], []
+    for t in range(T):
+        enc = torch.randn(B, 2 * L)
+        pri = torch.randn(B, 2 * L)
+        torch.manual_seed(1000 + t)
+        n_post = torch.zeros(B, L).normal_()
+        n_prior = torch.zeros(B, L).normal_()
+        torch.manual_seed(1000 + t)
+        z, params = V.reparameterize(Stub(), {'encoder_logits': enc, 'prior_logits': pri.clone(), 'x_features': None})
+        cfg['use_prior_kl'] = False
+        kl = V.kld(Stub(), params)
+        cfg['use_prior_kl'] = True
+        kl2 = V.kld(Stub(), params)
+        cfg['use_prior_kl'] = False
+        steps.append(detach_tree({'enc_logits': enc, 'prior_logits': pri, 'noise_post': n_post, 'noise_prior': n_prior,
+                                  'z_post': z['posterior'], 'z_prior': z['prior'], 'params': params, 'kld': kl,
+                                  'kld_with_prior_kl': kl2}))
+        losses.append({'loss': torch.rand(B), 'elbo': torch.rand(B), 'loss_mean': torch.rand(()),
+                       'kl_beta_scalar': 1.0})
+    agg = None
+    for lt in losses:
+        agg = V._add_loss_map({k: (v.clone() if torch.is_tensor(v) else v) for k, v in lt.items()}, agg)
+    agg = V._mean_map(agg)
+    out['vrnn'] = {'steps': steps, 'losses': detach_tree(losses), 'mean_map': detach_tree(agg)}
+
+
+def main():
+    vae = install_reference()
+    out = {}
+    make_gaussian(vae, out)
+    make_gumbel(vae, out)
+    make_bernoulli(vae, out)
+    make_beta(vae, out)
+    make_flow_kl(vae, out)
+    make_concat(vae, out)
+    make_sequential(vae, out)
+    make_elbo(vae, out)
+    make_vrnn(vae, out)
+    groups = {}
+    for k, v in out.items():
+        groups.setdefault(k.split('_')[0], {})[k] = v
+    for g, d in groups.items():
+        path = os.path.join(HERE, g + '.pt')
+        torch.save(d, path)
+        print('wrote %s (%d cases, %d bytes)' % (path, len(d), os.path.getsize(path)))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,196 @@
+"""Pin oracle/cpu_ref.py against outputs of the reference itself (tests/golden/*.pt).
+
+CPU only.  Where the op order is identical the comparison is bit-exact (torch.equal);
+elsewhere rtol 1e-6.
+"""
+import torch
+import pytest
+
+from oracle import cpu_ref as O
+
+
+def close(a, b, rtol=1e-6, atol=1e-7):
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize('name', ['gauss_L4_train', 'gauss_L4_eval', 'gauss_L32_train', 'gauss_L32_eval', 'gauss_3d'])
+def test_gaussian(golden, name):
+    g = golden('gauss')[name]
+    training = g.get('training', True)
+    logits = g['logits'].clone().requires_grad_(True)
+    z, params = O.gauss_forward(logits, g['noise'], training=training)
+    assert torch.equal(z, g['z'])
+    gp = g['params']['gaussian']
+    assert torch.equal(params['gaussian']['mu'], gp['mu'])
+    assert torch.equal(params['gaussian']['logvar'], gp['logvar'])
+    assert torch.equal(params['gaussian']['mu_mean'], gp['mu_mean'])
+    assert torch.equal(params['gaussian']['logvar_mean'], gp['logvar_mean'])
+    kl = O.gauss_kl(params)
+    assert torch.equal(kl, g['kl'])
+    if 'kl_prior' in g:
+        pl = g['prior_logits'].clone().requires_grad_(True)
+        _, pparams = O.gauss_forward(pl, g['noise'], training=training)
+        klp = O.gauss_kl(params, pparams)
+        assert torch.equal(klp, g['kl_prior'])
+        (gl,) = torch.autograd.grad((z * g['w']).sum() + kl.sum(), logits, retain_graph=True)
+        close(gl, g['grad_logits'])
+        gq, gpp = torch.autograd.grad(klp.sum(), [logits, pl])
+        close(gq, g['grad_klp_logits'])
+        close(gpp, g['grad_klp_prior_logits'])
+
+
+def test_gaussian_closed_form(golden):
+    """z = e*(0.5*s)+mu (no exp); KL = sum 0.5*(s^2 + mu^2 - 1 - log s^2), finite for s < 0."""
+    g = golden('gauss')['gauss_L32_train']
+    L = 32
+    mu, s = g['logits'][:, :L], g['logits'][:, L:] + g['eps_tol']
+    close(g['z'], g['noise'] * (0.5 * s) + mu, rtol=0, atol=0)
+    assert (s < 0).any()
+    close(g['kl'], (0.5 * (s * s + mu * mu - 1 - torch.log(s * s))).sum(-1), rtol=1e-5, atol=1e-5)
+
+
+GUMBEL = ['gumbel_K%d_%s_tau%g' % (K, m, t) for K in (5, 32) for m in ('train', 'eval') for t in (1.0, 0.5)]
+
+
+@pytest.mark.parametrize('name', GUMBEL + ['gumbel_ties'])
+def test_gumbel(golden, name):
+    g = golden('gumbel')[name]
+    logits = g['logits'].clone().requires_grad_(True)
+    z, params = O.gumbel_forward(logits, g['U'], tau=g['tau'], training=g['training'])
+    assert torch.equal(z, g['z'])
+    d, gd = params['discrete'], g['params']['discrete']
+    assert torch.equal(d['z_hard'], gd['z_hard'])
+    assert torch.equal(d['log_q_z'], gd['log_q_z'])
+    assert torch.equal(params['z'], g['params']['z'])
+    assert torch.equal((d['z_hard'] == 1).sum(-1), g['hard_count'])
+    if name == 'gumbel_ties':
+        assert int(g['hard_count'].max()) >= 2  # multi-hot on ties
+        return
+    assert torch.equal(d['z_hard'].argmax(-1), g['hard_index'])
+    kl0 = O.categorical_kl(params)
+    assert torch.equal(kl0, g['kl_none'])
+    assert float(kl0.detach().abs().max()) == 0.0  # KL(q||q)
+    pl = g['prior_logits'].clone().requires_grad_(True)
+    prior = {'discrete': {'log_q_z': torch.log_softmax(pl.clone(), -1)}}
+    assert torch.equal(prior['discrete']['log_q_z'], g['prior_log_q_z'])
+    klp = O.categorical_kl(params, prior)
+    assert torch.equal(klp, g['kl_prior'])
+    gl, gp = torch.autograd.grad((z * g['w']).sum() + klp.sum(), [logits, pl])
+    close(gl, g['grad_logits'])
+    close(gp, g['grad_prior_logits'])
+
+
+def test_gumbel_anneal(golden):
+    g = golden('gumbel')['gumbel_anneal']
+    tau, it, taus = 1.0, g['start_iteration'], []
+    for _ in range(25):
+        tau = O.anneal_tau(tau, it, True)
+        it += 1
+        taus.append(tau)
+    assert it == g['end_iteration']
+    assert taus == pytest.approx(g['taus'], rel=0, abs=0)
+
+
+BERN = ['bern_K%d_%s_tau%g' % (K, m, t) for K in (5, 32) for m in ('train', 'eval') for t in (1.0, 0.3)]
+
+
+@pytest.mark.parametrize('name', BERN)
+def test_bernoulli(golden, name):
+    g = golden('bern')[name]
+    logits = g['logits'].clone().requires_grad_(True)
+    z, params = O.bernoulli_forward(logits, g['U'], tau=g['tau'], training=g['training'])
+    close(z, g['z'], rtol=1e-6, atol=1e-7)
+    assert torch.equal(params['discrete']['z_hard'].detach().round(), g['params']['discrete']['z_hard'].round())
+    close(params['z'], g['params']['z'])
+    kl0 = O.bernoulli_kl(params)
+    close(kl0, g['kl_none'])
+    pl = g['prior_logits'].clone().requires_grad_(True)
+    klp = O.bernoulli_kl(params, {'discrete': {'logits': pl}})
+    close(klp, g['kl_prior'])
+    (gl,) = torch.autograd.grad((z * g['w']).sum() + kl0.sum(), logits, retain_graph=True)
+    close(gl, g['grad_logits'], rtol=1e-5, atol=1e-6)
+    gq, gp = torch.autograd.grad(klp.sum(), [logits, pl])
+    close(gq, g['grad_klp_logits'], rtol=1e-5, atol=1e-6)
+    close(gp, g['grad_klp_prior_logits'], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('name', ['beta_L4', 'beta_L32'])
+def test_beta(golden, name):
+    g = golden('beta')[name]
+    logits = g['logits'].clone().requires_grad_(True)
+    bp = O.beta_params(logits)
+    gb = g['params']['beta']
+    for k in ('conc1', 'conc2', 'conc1_mean', 'conc2_mean'):
+        assert torch.equal(bp[k], gb[k])
+    kl0 = O.beta_kl({'beta': bp})
+    assert torch.equal(kl0, g['kl_none'])
+    pl = g['prior_logits'].clone().requires_grad_(True)
+    klp = O.beta_kl({'beta': bp}, {'beta': O.beta_params(pl)})
+    assert torch.equal(klp, g['kl_prior'])
+    (g0,) = torch.autograd.grad(kl0.sum() + bp['conc1_mean'] + 2 * bp['conc2_mean'], logits, retain_graph=True)
+    close(g0, g['grad_kl0_means_logits'])
+    gq, gp = torch.autograd.grad(klp.sum(), [logits, pl])
+    close(gq, g['grad_klp_logits'])
+    close(gp, g['grad_klp_prior_logits'])
+
+
+@pytest.mark.parametrize('name', ['flowkl_2d', 'flowkl_3d'])
+def test_flow_kl(golden, name):
+    g = golden('flowkl')[name]
+    u = g['u'].clone().requires_grad_(True)
+    ld = g['logdet'].clone().requires_grad_(True)
+    kl = O.flow_kl({'recon_x': u, 'logdet': ld})
+    assert torch.equal(kl, g['kl'])
+    gu, gl = torch.autograd.grad((kl * g['w']).sum(), [u, ld])
+    close(gu, g['grad_u'])
+    close(gl, g['grad_logdet'])
+    if name == 'flowkl_2d':
+        # the cross-batch mean
+        lp = (-0.5 * g['u'] ** 2 - 0.9189385332046727).sum(-1)
+        close(g['kl'], (-lp).mean() - g['logdet'][:, 0], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('name', ['concat_train', 'concat_eval'])
+def test_concat(golden, name):
+    g = golden('concat')[name]
+    L, K = 4, 5
+    logits = g['logits'].clone().requires_grad_(True)
+    children = [('isotropic_gaussian', 2 * L, {}), ('discrete', K, {'tau': 1.0})]
+    z, params = O.concat_forward(logits, children, [g['noise'], g['U']], training=g['training'])
+    assert torch.equal(z, g['z'])
+    assert z.shape[-1] == g['output_size'] and logits.shape[-1] == g['input_size']
+    kl = O.concat_kl(params, ['isotropic_gaussian', 'discrete'])
+    assert torch.equal(kl, g['kl'])
+    for mine, ref in zip(params['concat'], g['params']['concat']):
+        assert torch.equal(mine['logits'], ref['logits'])
+    assert torch.equal(params['concat'][1]['discrete']['z_hard'], g['params']['concat'][1]['discrete']['z_hard'])
+    (gl,) = torch.autograd.grad((z * g['w']).sum() + kl.sum(), logits)
+    close(gl, g['grad_logits'])
+
+
+@pytest.mark.parametrize('name', ['elbo_beta1_plain', 'elbo_beta0.25_extra'])
+def test_elbo_combine(golden, name):
+    g = golden('elbo')[name]
+    res = O.loss_function(g['nll'], g['kld'], g['kl_beta'], extra=g['extra'])
+    for k, v in g['result'].items():
+        if torch.is_tensor(v):
+            assert torch.equal(res[k], v), k
+        else:
+            assert res[k] == v
+
+
+def test_vrnn(golden):
+    g = golden('vrnn')['vrnn']
+    for s in g['steps']:
+        z, params = O.vrnn_reparameterize(s['enc_logits'], s['prior_logits'], s['noise_post'], s['noise_prior'])
+        assert torch.equal(z['posterior'], s['z_post'])
+        assert torch.equal(z['prior'], s['z_prior'])
+        assert torch.equal(params['prior']['gaussian']['logvar'], s['params']['prior']['gaussian']['logvar'])
+        assert torch.equal(O.vrnn_kld(params, False), s['kld'])
+        assert torch.equal(O.vrnn_kld(params, True), s['kld_with_prior_kl'])
+    agg = O.vrnn_loss(g['losses'])
+    for k, v in g['mean_map'].items():
+        if torch.is_tensor(v):
+            close(agg[k], v, rtol=1e-6, atol=0)
+        else:
+            assert agg[k] == pytest.approx(v)

@@ -1,0 +1,114 @@
+"""ctypes binding of libvae_amd.so (the C ABI declared in include/vae_amd.h).
+
+The library holds only HIP kernels + `extern "C"` launchers (no torch headers);
+torch is used here for device memory and the current HIP stream, nothing else.
+`import torch` must happen before the library is opened so that both resolve the
+same `libamdhip64.so.7` (torch ships its own copy; the soname is shared).
+
+There is NO CPU fallback: a missing library or a CPU tensor raises.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported before the CDLL below, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libvae_amd.so')
+ABI_VERSION = 1
+
+VAE_OK, VAE_ERR_ARG, VAE_ERR_LAUNCH = 0, 1, 2
+VAE_F32, VAE_BF16 = 0, 1
+NLL_TYPES = {'bernoulli': 0, 'gaussian': 1, 'disc_logistic': 2, 'log_logistic_256': 2}
+
+_p, _i64, _u64, _f, _i = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, ctypes.c_int
+
+# name -> argtypes; mirrors include/vae_amd.h one to one (tests/test_abi.py checks the symbols)
+SIGNATURES = {
+    'vae_abi_version': [],
+    'vae_workspace_bytes': [],
+    'vae_gauss_reparam_kl_fwd': [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _f, _f, _i, _u64, _u64, _i64, _i, _p],
+    'vae_gauss_reparam_kl_bwd': [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _f, _f, _i, _u64, _u64, _i64, _i, _p],
+    'vae_gauss_kl_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i, _p],
+    'vae_gauss_kl_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
+    'vae_nll_elbo_fwd': [_p, _p, _i, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
+    'vae_nll_elbo_bwd': [_p, _p, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i64, _i, _p],
+    'vae_elbo_combine_fwd': [_p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i, _p],
+    'vae_elbo_combine_bwd': [_p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i, _p],
+}
+
+_lib = None
+
+
+def load():
+    """Open libvae_amd.so (once).  Raises if it was not built: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "vae_amd: %s is missing; build it with `make -C vae_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no CPU/eager fallback for this path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_size_t if name == 'vae_workspace_bytes' else ctypes.c_int
+    if lib.vae_abi_version() != ABI_VERSION:
+        raise RuntimeError("vae_amd: libvae_amd.so has ABI %d, the binding expects %d; rebuild"
+                           % (lib.vae_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return VAE_F32
+    if t.dtype == torch.bfloat16:
+        return VAE_BF16
+    raise TypeError("vae_amd kernels take float32 or bfloat16 tensors, got %s" % t.dtype)
+
+
+def check_device(*tensors):
+    """All given (non-None) tensors must live on one ROCm device; returns it."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("vae_amd: tensor on %s; the HIP path has no CPU fallback "
+                               "(use oracle/cpu_ref.py only as a test oracle)" % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("vae_amd: tensors on different devices (%s vs %s)" % (dev, t.device))
+    return dev
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_workspaces = {}
+
+
+def workspace(device):
+    """Per (device, stream) scratch for block partials; one call at a time per stream."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None:
+        nbytes = load().vae_workspace_bytes()
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != VAE_OK:
+        what = {VAE_ERR_ARG: 'invalid argument', VAE_ERR_LAUNCH: 'kernel launch failed'}.get(rc, 'error %d' % rc)
+        raise RuntimeError("vae_amd: %s: %s" % (name, what))

@@ -1,0 +1,422 @@
+// Per-sample NLL + ELBO, fused (forward and backward).
+//
+// Replaces, from /root/reference:
+//   abstract_vae.py:461-471   nll(x, recon_x, nll_type) -> [B]   (delegates to the
+//                             un-vendored helpers.distributions.nll; the three
+//                             definitions below are this build's stated contract,
+//                             "parity unpinned" -- see oracle/cpu_ref.py)
+//   abstract_vae.py:356-388   elbo = nll + kld; loss = (nll + add + beta*kld) - mi;
+//                             the six torch.mean() calls of the returned dict
+//   abstract_vae.py:15-37     VarianceProjector layout: for NLLs with a variance the
+//                             decoder row is [mean(D) | variance-param(D)]
+//
+// HBM-bound: the forward reads 4D (x) + 4D or 8D (recon) bytes per sample and
+// writes 12 bytes; the backward reads the same and writes 4D or 8D.  A row is
+// owned by G lanes (G <= 64: shuffles only) or by the whole block (G = 256: wave
+// shuffles, then LDS across the four waves) when rows are long and few.
+#include "common.hpp"
+#include "../../include/vae_amd.h"
+
+namespace vae {
+
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;
+constexpr float kBin = 1.0f / 256.0f;
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+__device__ __forceinline__ float softplusf_(float v) {
+  // torch.nn.functional.softplus: linear above threshold 20
+  return v > 20.0f ? v : log1pf(expf(v));
+}
+
+// ---- the three NLLs: value and d/d(recon) per element --------------------------
+// NLL == VAE_NLL_BERNOULLI: -Bernoulli(logits=l).log_prob(x) = max(l,0) - l*x + log1p(exp(-|l|))
+__device__ __forceinline__ float nll_bern(float x, float l) {
+  return fmaxf(l, 0.0f) - l * x + log1pf(expf(-fabsf(l)));
+}
+__device__ __forceinline__ float nll_bern_grad(float x, float l) { return sigmoidf_(l) - x; }
+
+// NLL == VAE_NLL_GAUSSIAN: -Normal(m, softplus(v) + 1e-6).log_prob(x)
+__device__ __forceinline__ float nll_gauss(float x, float m, float v) {
+  float s = softplusf_(v) + 1e-6f;
+  float d = (x - m) / s;
+  return 0.5f * d * d + logf(s) + kHalfLog2Pi;
+}
+__device__ __forceinline__ void nll_gauss_grad(float x, float m, float v, float& gm, float& gv) {
+  float s = softplusf_(v) + 1e-6f;
+  float is = 1.0f / s;
+  float d = (x - m) * is;
+  gm = -d * is;
+  gv = (is - d * d * is) * sigmoidf_(v);
+}
+
+// NLL == VAE_NLL_DISC_LOGISTIC (256 bins): xq = floor(x*256)/256, m = sigmoid(a),
+// lv = clamp(v, -4.5, 0), sc = exp(lv), t = (xq - m)/sc,
+// -log(sigmoid(t + bin/sc) - sigmoid(t) + 1e-7)
+__device__ __forceinline__ float nll_dlog(float x, float a, float v) {
+  float xq = floorf(x / kBin) * kBin;
+  float m = sigmoidf_(a);
+  float lv = fminf(fmaxf(v, -4.5f), 0.0f);
+  float sc = expf(lv);
+  float t = (xq - m) / sc;
+  float cp = sigmoidf_(t + kBin / sc);
+  float cm = sigmoidf_(t);
+  return -logf(cp - cm + 1e-7f);
+}
+__device__ __forceinline__ void nll_dlog_grad(float x, float a, float v, float& ga, float& gv) {
+  float xq = floorf(x / kBin) * kBin;
+  float m = sigmoidf_(a);
+  float lv = fminf(fmaxf(v, -4.5f), 0.0f);
+  float sc = expf(lv);
+  float isc = 1.0f / sc;
+  float t = (xq - m) * isc;
+  float tp = t + kBin * isc;
+  float cp = sigmoidf_(tp);
+  float cm = sigmoidf_(t);
+  float ip = 1.0f / (cp - cm + 1e-7f);
+  float dp = -cp * (1.0f - cp) * ip;  // d nll / d tp
+  float dm = cm * (1.0f - cm) * ip;   // d nll / d t
+  ga = (dp + dm) * (-isc) * m * (1.0f - m);
+  float inside = (v > -4.5f && v < 0.0f) ? 1.0f : 0.0f;  // hardtanh passes no gradient at the clamps
+  gv = (dp * (-tp) + dm * (-t)) * inside;
+}
+
+// Row reduction for either geometry.  G <= 64: butterfly inside the lane group.
+// G == kBlock: the whole block owns the row (uniform control flow required).
+__device__ __forceinline__ float row_sum(float v, int G) {
+  if (G <= 64) return group_sum(v, G);
+  __shared__ float lds[kBlock / 64];
+  v = wave_sum(v);
+  __syncthreads();  // protect lds from the previous row's readers
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) s += lds[w];
+  return s;
+}
+
+// ---------------------------------------------------------------------------
+// forward: nll[B] (+ loss[B], elbo[B], block partials of the six sums)
+// ---------------------------------------------------------------------------
+template <typename T, int V, int NLL>
+__global__ __launch_bounds__(kBlock) void nll_elbo_fwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ recon, const T* __restrict__ kld, const T* __restrict__ add,
+    const T* __restrict__ mi, T* __restrict__ nll_out, T* __restrict__ loss, T* __restrict__ elbo,
+    float* __restrict__ partials, int64_t B, int D, float kl_beta, int G, int64_t tiles) {
+  const int rpb = kBlock / G;
+  const int sub = threadIdx.x % G;
+  const int rloc = threadIdx.x / G;
+  const int nvec = D / V;
+  const int64_t rstride = (NLL == VAE_NLL_BERNOULLI) ? (int64_t)D : 2 * (int64_t)D;
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t row = t * rpb + rloc;
+    float s = 0.f;
+    if (row < B) {
+      const T* xr = x + row * D;
+      const T* rr = recon + row * rstride;
+#pragma unroll 4
+      for (int j = sub; j < nvec; j += G) {
+        float xv[V], a[V], b[V];
+        load_vec<T, V>(xr + (int64_t)j * V, xv);
+        load_vec<T, V>(rr + (int64_t)j * V, a);
+        if constexpr (NLL != VAE_NLL_BERNOULLI) load_vec<T, V>(rr + D + (int64_t)j * V, b);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          if constexpr (NLL == VAE_NLL_BERNOULLI) s += nll_bern(xv[i], a[i]);
+          if constexpr (NLL == VAE_NLL_GAUSSIAN) s += nll_gauss(xv[i], a[i], b[i]);
+          if constexpr (NLL == VAE_NLL_DISC_LOGISTIC) s += nll_dlog(xv[i], a[i], b[i]);
+        }
+      }
+    }
+    s = row_sum(s, G);
+    if (row < B && sub == 0) {
+      // round through the tensor dtype where the reference materialises a tensor
+      const float n = to_f32(from_f32<T>(s));
+      nll_out[row] = from_f32<T>(n);
+      if (loss) {
+        const float k = kld ? to_f32(kld[row]) : 0.f;
+        const float ad = add ? to_f32(add[row]) : 0.f;
+        const float m = mi ? to_f32(mi[row]) : 0.f;
+        const float e = to_f32(from_f32<T>(n + k));
+        const float l = to_f32(from_f32<T>((n + ad + kl_beta * k) - m));
+        loss[row] = from_f32<T>(l);
+        elbo[row] = from_f32<T>(e);
+        acc[0] += l; acc[1] += e; acc[2] += n; acc[3] += k; acc[4] += ad; acc[5] += m;
+      }
+    }
+  }
+  if (partials) block_partials<6>(acc, partials);
+}
+
+// ---------------------------------------------------------------------------
+// backward: d recon (and the [B]-sized d kld / d add / d mi)
+//   c_nll[b] = gnll[b] + gloss[b] + gelbo[b] + (gm_loss + gm_elbo + gm_nll) * inv_count
+// ---------------------------------------------------------------------------
+template <typename T, int V, int NLL>
+__global__ __launch_bounds__(kBlock) void nll_elbo_bwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ recon, const T* __restrict__ gnll, const T* __restrict__ gloss,
+    const T* __restrict__ gelbo, const float* __restrict__ gmeans, T* __restrict__ grecon, T* __restrict__ gkld,
+    T* __restrict__ gadd, T* __restrict__ gmi, int64_t B, int D, float kl_beta, float inv_count, int G,
+    int64_t tiles) {
+  const int rpb = kBlock / G;
+  const int sub = threadIdx.x % G;
+  const int rloc = threadIdx.x / G;
+  const int nvec = D / V;
+  const int64_t rstride = (NLL == VAE_NLL_BERNOULLI) ? (int64_t)D : 2 * (int64_t)D;
+  float gm[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) gm[k] = gmeans ? gmeans[k] * inv_count : 0.f;
+
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t row = t * rpb + rloc;
+    if (row >= B) continue;
+    const float gl = (gloss ? to_f32(gloss[row]) : 0.f) + gm[0];
+    const float ge = (gelbo ? to_f32(gelbo[row]) : 0.f) + gm[1];
+    const float c = (gnll ? to_f32(gnll[row]) : 0.f) + gl + ge + gm[2];
+    if (sub == 0) {
+      if (gkld) gkld[row] = from_f32<T>(kl_beta * gl + ge + gm[3]);
+      if (gadd) gadd[row] = from_f32<T>(gl + gm[4]);
+      if (gmi) gmi[row] = from_f32<T>(gm[5] - gl);
+    }
+    const T* xr = x + row * D;
+    const T* rr = recon + row * rstride;
+    T* gr = grecon + row * rstride;
+#pragma unroll 4
+    for (int j = sub; j < nvec; j += G) {
+      float xv[V], a[V], b[V], ga[V], gb[V];
+      load_vec<T, V>(xr + (int64_t)j * V, xv);
+      load_vec<T, V>(rr + (int64_t)j * V, a);
+      if constexpr (NLL != VAE_NLL_BERNOULLI) load_vec<T, V>(rr + D + (int64_t)j * V, b);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        if constexpr (NLL == VAE_NLL_BERNOULLI) ga[i] = c * nll_bern_grad(xv[i], a[i]);
+        if constexpr (NLL == VAE_NLL_GAUSSIAN) {
+          nll_gauss_grad(xv[i], a[i], b[i], ga[i], gb[i]);
+          ga[i] *= c; gb[i] *= c;
+        }
+        if constexpr (NLL == VAE_NLL_DISC_LOGISTIC) {
+          nll_dlog_grad(xv[i], a[i], b[i], ga[i], gb[i]);
+          ga[i] *= c; gb[i] *= c;
+        }
+      }
+      store_vec<T, V>(gr + (int64_t)j * V, ga);
+      if constexpr (NLL != VAE_NLL_BERNOULLI) store_vec<T, V>(gr + D + (int64_t)j * V, gb);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// ELBO combine from a given nll[B] (K>1 Monte-Carlo average, VRNN per-step dicts):
+// one thread per sample.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void elbo_combine_fwd_kernel(
+    const T* __restrict__ nll, const T* __restrict__ kld, const T* __restrict__ add, const T* __restrict__ mi,
+    T* __restrict__ loss, T* __restrict__ elbo, float* __restrict__ partials, int64_t B, float kl_beta) {
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < B; row += (int64_t)gridDim.x * kBlock) {
+    const float n = to_f32(nll[row]);
+    const float k = kld ? to_f32(kld[row]) : 0.f;
+    const float ad = add ? to_f32(add[row]) : 0.f;
+    const float m = mi ? to_f32(mi[row]) : 0.f;
+    const float e = to_f32(from_f32<T>(n + k));
+    const float l = to_f32(from_f32<T>((n + ad + kl_beta * k) - m));
+    loss[row] = from_f32<T>(l);
+    elbo[row] = from_f32<T>(e);
+    acc[0] += l; acc[1] += e; acc[2] += n; acc[3] += k; acc[4] += ad; acc[5] += m;
+  }
+  block_partials<6>(acc, partials);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void elbo_combine_bwd_kernel(
+    const T* __restrict__ gloss, const T* __restrict__ gelbo, const float* __restrict__ gmeans, T* __restrict__ gnll,
+    T* __restrict__ gkld, T* __restrict__ gadd, T* __restrict__ gmi, int64_t B, float kl_beta, float inv_count) {
+  float gm[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) gm[k] = gmeans ? gmeans[k] * inv_count : 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < B; row += (int64_t)gridDim.x * kBlock) {
+    const float gl = (gloss ? to_f32(gloss[row]) : 0.f) + gm[0];
+    const float ge = (gelbo ? to_f32(gelbo[row]) : 0.f) + gm[1];
+    if (gnll) gnll[row] = from_f32<T>(gl + ge + gm[2]);
+    if (gkld) gkld[row] = from_f32<T>(kl_beta * gl + ge + gm[3]);
+    if (gadd) gadd[row] = from_f32<T>(gl + gm[4]);
+    if (gmi) gmi[row] = from_f32<T>(gm[5] - gl);
+  }
+}
+
+void launch_finalize(const float* partials, int nblocks, int n, float scale, float* out, hipStream_t stream);
+
+// Long rows with few samples: give a row to the whole block so the chip stays full.
+static RowGeom nll_geom(int64_t B, int64_t vecs_per_row) {
+  RowGeom g = row_geom(B, vecs_per_row);
+  if (vecs_per_row >= 1024 && g.tiles < 4 * 256) {
+    g.G = kBlock;
+    g.rows_per_block = 1;
+    g.tiles = B;
+    g.grid = (int)(g.tiles < kMaxGrid ? g.tiles : kMaxGrid);
+  }
+  return g;
+}
+
+template <typename T, int NLL>
+static int nll_fwd_dispatch(const void* x, const void* recon, const void* kld, const void* add, const void* mi,
+                            void* nll, void* loss, void* elbo, float* means, float* workspace, int64_t B, int64_t D,
+                            float kl_beta, float inv_count, hipStream_t stream) {
+  constexpr int VN = VecOf<T>::n;
+  const bool vec = (D % VN == 0) && aligned16(x) && aligned16(recon);
+  const RowGeom g = nll_geom(B, vec ? D / VN : D);
+  float* partials = loss ? workspace : nullptr;
+  if (vec) {
+    hipLaunchKernelGGL((nll_elbo_fwd_kernel<T, VN, NLL>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)x,
+                       (const T*)recon, (const T*)kld, (const T*)add, (const T*)mi, (T*)nll, (T*)loss, (T*)elbo,
+                       partials, B, (int)D, kl_beta, g.G, g.tiles);
+  } else {
+    hipLaunchKernelGGL((nll_elbo_fwd_kernel<T, 1, NLL>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)x,
+                       (const T*)recon, (const T*)kld, (const T*)add, (const T*)mi, (T*)nll, (T*)loss, (T*)elbo,
+                       partials, B, (int)D, kl_beta, g.G, g.tiles);
+  }
+  if (loss && means) launch_finalize(workspace, g.grid, 6, inv_count, means, stream);
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+template <typename T, int NLL>
+static int nll_bwd_dispatch(const void* x, const void* recon, const void* gnll, const void* gloss, const void* gelbo,
+                            const float* gmeans, void* grecon, void* gkld, void* gadd, void* gmi, int64_t B,
+                            int64_t D, float kl_beta, float inv_count, hipStream_t stream) {
+  constexpr int VN = VecOf<T>::n;
+  const bool vec = (D % VN == 0) && aligned16(x) && aligned16(recon) && aligned16(grecon);
+  RowGeom g = nll_geom(B, vec ? D / VN : D);
+  if (vec) {
+    hipLaunchKernelGGL((nll_elbo_bwd_kernel<T, VN, NLL>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)x,
+                       (const T*)recon, (const T*)gnll, (const T*)gloss, (const T*)gelbo, gmeans, (T*)grecon,
+                       (T*)gkld, (T*)gadd, (T*)gmi, B, (int)D, kl_beta, inv_count, g.G, g.tiles);
+  } else {
+    hipLaunchKernelGGL((nll_elbo_bwd_kernel<T, 1, NLL>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)x,
+                       (const T*)recon, (const T*)gnll, (const T*)gloss, (const T*)gelbo, gmeans, (T*)grecon,
+                       (T*)gkld, (T*)gadd, (T*)gmi, B, (int)D, kl_beta, inv_count, g.G, g.tiles);
+  }
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+template <typename T>
+static int nll_fwd_type(int nll_type, const void* x, const void* recon, const void* kld, const void* add,
+                        const void* mi, void* nll, void* loss, void* elbo, float* means, float* workspace, int64_t B,
+                        int64_t D, float kl_beta, float inv_count, hipStream_t st) {
+  switch (nll_type) {
+    case VAE_NLL_BERNOULLI:
+      return nll_fwd_dispatch<T, VAE_NLL_BERNOULLI>(x, recon, kld, add, mi, nll, loss, elbo, means, workspace, B, D,
+                                                    kl_beta, inv_count, st);
+    case VAE_NLL_GAUSSIAN:
+      return nll_fwd_dispatch<T, VAE_NLL_GAUSSIAN>(x, recon, kld, add, mi, nll, loss, elbo, means, workspace, B, D,
+                                                   kl_beta, inv_count, st);
+    case VAE_NLL_DISC_LOGISTIC:
+      return nll_fwd_dispatch<T, VAE_NLL_DISC_LOGISTIC>(x, recon, kld, add, mi, nll, loss, elbo, means, workspace, B,
+                                                        D, kl_beta, inv_count, st);
+  }
+  return VAE_ERR_ARG;
+}
+
+template <typename T>
+static int nll_bwd_type(int nll_type, const void* x, const void* recon, const void* gnll, const void* gloss,
+                        const void* gelbo, const float* gmeans, void* grecon, void* gkld, void* gadd, void* gmi,
+                        int64_t B, int64_t D, float kl_beta, float inv_count, hipStream_t st) {
+  switch (nll_type) {
+    case VAE_NLL_BERNOULLI:
+      return nll_bwd_dispatch<T, VAE_NLL_BERNOULLI>(x, recon, gnll, gloss, gelbo, gmeans, grecon, gkld, gadd, gmi, B,
+                                                    D, kl_beta, inv_count, st);
+    case VAE_NLL_GAUSSIAN:
+      return nll_bwd_dispatch<T, VAE_NLL_GAUSSIAN>(x, recon, gnll, gloss, gelbo, gmeans, grecon, gkld, gadd, gmi, B,
+                                                   D, kl_beta, inv_count, st);
+    case VAE_NLL_DISC_LOGISTIC:
+      return nll_bwd_dispatch<T, VAE_NLL_DISC_LOGISTIC>(x, recon, gnll, gloss, gelbo, gmeans, grecon, gkld, gadd,
+                                                        gmi, B, D, kl_beta, inv_count, st);
+  }
+  return VAE_ERR_ARG;
+}
+
+}  // namespace vae
+
+using namespace vae;
+
+extern "C" {
+
+int vae_nll_elbo_fwd(const void* x, const void* recon, int nll_type, const void* kld, const void* add, const void* mi,
+                     float kl_beta, float inv_count, void* nll, void* loss, void* elbo, float* means,
+                     float* workspace, int64_t B, int64_t D, int dtype, vae_stream_t stream) {
+  if (!x || !recon || !nll || B < 0 || D <= 0 || D > VAE_MAX_ROW) return VAE_ERR_ARG;
+  if ((loss == nullptr) != (elbo == nullptr)) return VAE_ERR_ARG;
+  if (loss && !workspace) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VAE_F32)
+    return nll_fwd_type<float>(nll_type, x, recon, kld, add, mi, nll, loss, elbo, means, workspace, B, D, kl_beta,
+                               inv_count, st);
+  if (dtype == VAE_BF16)
+    return nll_fwd_type<bf16_t>(nll_type, x, recon, kld, add, mi, nll, loss, elbo, means, workspace, B, D, kl_beta,
+                                inv_count, st);
+  return VAE_ERR_ARG;
+}
+
+int vae_nll_elbo_bwd(const void* x, const void* recon, int nll_type, const void* gnll, const void* gloss,
+                     const void* gelbo, const float* gmeans, float kl_beta, float inv_count, void* grecon, void* gkld,
+                     void* gadd, void* gmi, int64_t B, int64_t D, int dtype, vae_stream_t stream) {
+  if (!x || !recon || !grecon || B < 0 || D <= 0 || D > VAE_MAX_ROW) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VAE_F32)
+    return nll_bwd_type<float>(nll_type, x, recon, gnll, gloss, gelbo, gmeans, grecon, gkld, gadd, gmi, B, D,
+                               kl_beta, inv_count, st);
+  if (dtype == VAE_BF16)
+    return nll_bwd_type<bf16_t>(nll_type, x, recon, gnll, gloss, gelbo, gmeans, grecon, gkld, gadd, gmi, B, D,
+                                kl_beta, inv_count, st);
+  return VAE_ERR_ARG;
+}
+
+int vae_elbo_combine_fwd(const void* nll, const void* kld, const void* add, const void* mi, float kl_beta,
+                         float inv_count, void* loss, void* elbo, float* means, float* workspace, int64_t B,
+                         int dtype, vae_stream_t stream) {
+  if (!nll || !loss || !elbo || !workspace || B < 0) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t blocks = (B + kBlock - 1) / kBlock;
+  const int grid = (int)(blocks < kMaxGrid ? blocks : kMaxGrid);
+  if (dtype == VAE_F32) {
+    hipLaunchKernelGGL((elbo_combine_fwd_kernel<float>), dim3(grid), dim3(kBlock), 0, st, (const float*)nll,
+                       (const float*)kld, (const float*)add, (const float*)mi, (float*)loss, (float*)elbo, workspace,
+                       B, kl_beta);
+  } else if (dtype == VAE_BF16) {
+    hipLaunchKernelGGL((elbo_combine_fwd_kernel<bf16_t>), dim3(grid), dim3(kBlock), 0, st, (const bf16_t*)nll,
+                       (const bf16_t*)kld, (const bf16_t*)add, (const bf16_t*)mi, (bf16_t*)loss, (bf16_t*)elbo,
+                       workspace, B, kl_beta);
+  } else {
+    return VAE_ERR_ARG;
+  }
+  if (means) launch_finalize(workspace, grid, 6, inv_count, means, st);
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+int vae_elbo_combine_bwd(const void* gloss, const void* gelbo, const float* gmeans, float kl_beta, float inv_count,
+                         void* gnll, void* gkld, void* gadd, void* gmi, int64_t B, int dtype, vae_stream_t stream) {
+  if (B < 0) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t blocks = (B + kBlock - 1) / kBlock;
+  const int grid = (int)(blocks < kMaxGrid ? blocks : kMaxGrid);
+  if (dtype == VAE_F32) {
+    hipLaunchKernelGGL((elbo_combine_bwd_kernel<float>), dim3(grid), dim3(kBlock), 0, st, (const float*)gloss,
+                       (const float*)gelbo, gmeans, (float*)gnll, (float*)gkld, (float*)gadd, (float*)gmi, B, kl_beta,
+                       inv_count);
+  } else if (dtype == VAE_BF16) {
+    hipLaunchKernelGGL((elbo_combine_bwd_kernel<bf16_t>), dim3(grid), dim3(kBlock), 0, st, (const bf16_t*)gloss,
+                       (const bf16_t*)gelbo, gmeans, (bf16_t*)gnll, (bf16_t*)gkld, (bf16_t*)gadd, (bf16_t*)gmi, B,
+                       kl_beta, inv_count);
+  } else {
+    return VAE_ERR_ARG;
+  }
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+}  // extern "C"

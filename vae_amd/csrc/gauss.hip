@@ -1,0 +1,411 @@
+// IsotropicGaussian reparameterize + KL, fused (forward and backward).
+//
+// Replaces the op chain of /root/reference reparameterizers/isotropic_gaussian.py:
+//   :123-125  mu = logits[..., :L]; s = logits[..., L:] + eps_tol
+//   :86-93    std = 0.5*s (NO exp); e ~ N(0,1); z = e*std + mu      (train / force)
+//   :96       z = mu                                               (eval)
+//   :168-170  KL(N(mu,s) || N(0,1)) = sum_j 0.5*(s^2 + mu^2 - 1 - log(s^2))
+//   :186-190  KL(N(mu_q,s_q) || N(mu_p,s_p)) (torch/distributions/kl.py:468-471)
+//   :213-214  mu_mean, logvar_mean
+// and of vrnn.py:395-417 (_clamp_variance: s_p = sigmoid(raw)) for the pair form.
+//
+// HBM-bound: per sample the forward reads 8L (logits) [+4L noise], writes 4L (z)
+// [+4L logvar] + 4 (kl).  One group of G lanes per row, 16 B per lane per access.
+#include "common.hpp"
+#include "../../include/vae_amd.h"
+
+namespace vae {
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+template <typename T, int V>
+__global__ __launch_bounds__(kBlock) void gauss_fwd_kernel(
+    const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ noise, T* __restrict__ z,
+    T* __restrict__ s_out, T* __restrict__ kl, float* __restrict__ partials, int64_t B, int L, float eps_tol,
+    int training, uint64_t seed, uint64_t offset, int64_t row0, int G, int64_t tiles) {
+  const int rpb = kBlock / G;
+  const int sub = threadIdx.x % G;
+  const int rloc = threadIdx.x / G;
+  const int nvec = L / V;
+  float acc[2] = {0.f, 0.f};  // sum mu, sum s over this thread's elements
+
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t row = t * rpb + rloc;
+    float klr = 0.f;
+    if (row < B) {
+      const T* lrow = logits + row * row_stride;
+#pragma unroll 2
+      for (int j = sub; j < nvec; j += G) {
+        float mu[V], s[V], e[V], zz[V];
+        load_vec<T, V>(lrow + (int64_t)j * V, mu);
+        load_vec<T, V>(lrow + L + (int64_t)j * V, s);
+        if (training) {
+          if (noise) {
+            load_vec<T, V>(noise + row * L + (int64_t)j * V, e);
+          } else {
+            philox_normal<V>(seed, offset, (uint64_t)(row0 + row) * (uint64_t)L + (uint64_t)j * V, e);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          // logvar = raw + eps_tol, rounded to the tensor dtype as the reference's add does
+          float si = to_f32(from_f32<T>(__fadd_rn(s[i], eps_tol)));
+          s[i] = si;
+          float m = mu[i];
+          // z = fl(fl(e * fl(0.5*s)) + mu): two roundings, no fma, as eps.mul(std).add_(mu)
+          zz[i] = training ? __fadd_rn(__fmul_rn(e[i], to_f32(from_f32<T>(0.5f * si))), m) : m;
+          float s2 = si * si;
+          klr += 0.5f * (s2 + m * m - 1.0f - logf(s2));
+          acc[0] += m;
+          acc[1] += si;
+        }
+        if (z) store_vec<T, V>(z + row * L + (int64_t)j * V, zz);
+        if (s_out) store_vec<T, V>(s_out + row * L + (int64_t)j * V, s);
+      }
+    }
+    klr = group_sum(klr, G);
+    if (row < B && sub == 0) kl[row] = from_f32<T>(klr);
+  }
+  block_partials<2>(acc, partials);
+}
+
+// ---------------------------------------------------------------------------
+// backward: d logits from d z, d logvar, d kl and the two mean diagnostics
+// ---------------------------------------------------------------------------
+template <typename T, int V>
+__global__ __launch_bounds__(kBlock) void gauss_bwd_kernel(
+    const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ noise, const T* __restrict__ gz,
+    const T* __restrict__ gs, const T* __restrict__ gkl, const float* __restrict__ gmeans, T* __restrict__ glogits,
+    int64_t B, int L, float eps_tol, float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0,
+    int G, int64_t tiles, int with_kl) {
+  const int rpb = kBlock / G;
+  const int sub = threadIdx.x % G;
+  const int rloc = threadIdx.x / G;
+  const int nvec = L / V;
+  const float gm_mu = gmeans ? gmeans[0] * mean_scale : 0.f;
+  const float gm_s = gmeans ? gmeans[1] * mean_scale : 0.f;
+
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t row = t * rpb + rloc;
+    if (row >= B) continue;
+    const T* lrow = logits + row * row_stride;
+    T* grow = glogits + row * 2 * (int64_t)L;
+    const float gk = (gkl && with_kl) ? to_f32(gkl[row]) : 0.f;
+#pragma unroll 2
+    for (int j = sub; j < nvec; j += G) {
+      float mu[V], s[V], e[V], g[V], g2[V], dmu[V], ds[V];
+      load_vec<T, V>(lrow + (int64_t)j * V, mu);
+      load_vec<T, V>(lrow + L + (int64_t)j * V, s);
+      if (gz) {
+        load_vec<T, V>(gz + row * L + (int64_t)j * V, g);
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) g[i] = 0.f;
+      }
+      if (gs) {
+        load_vec<T, V>(gs + row * L + (int64_t)j * V, g2);
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) g2[i] = 0.f;
+      }
+      if (training) {
+        if (noise) {
+          load_vec<T, V>(noise + row * L + (int64_t)j * V, e);
+        } else {
+          philox_normal<V>(seed, offset, (uint64_t)(row0 + row) * (uint64_t)L + (uint64_t)j * V, e);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        float si = to_f32(from_f32<T>(__fadd_rn(s[i], eps_tol)));
+        dmu[i] = g[i] + gk * mu[i] + gm_mu;
+        ds[i] = (training ? 0.5f * e[i] * g[i] : 0.f) + g2[i] + gk * (si - 1.0f / si) + gm_s;
+      }
+      store_vec<T, V>(grow + (int64_t)j * V, dmu);
+      store_vec<T, V>(grow + L + (int64_t)j * V, ds);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// standalone KL between two Gaussians given as strided (mu, scale) views; the
+// prior may be absent (N(0,1)).  Used when kl() is called on params that did not
+// come from the fused forward (VRNN posterior-vs-prior, class-conditioned prior).
+// ---------------------------------------------------------------------------
+template <typename T, int V>
+__global__ __launch_bounds__(kBlock) void gauss_kl_fwd_kernel(
+    const T* __restrict__ mu_q, int64_t sq_mu, const T* __restrict__ s_q, int64_t sq_s, const T* __restrict__ mu_p,
+    int64_t sp_mu, const T* __restrict__ s_p, int64_t sp_s, T* __restrict__ kl, int64_t B, int L, int G,
+    int64_t tiles) {
+  const int rpb = kBlock / G;
+  const int sub = threadIdx.x % G;
+  const int rloc = threadIdx.x / G;
+  const int nvec = L / V;
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t row = t * rpb + rloc;
+    float klr = 0.f;
+    if (row < B) {
+#pragma unroll 2
+      for (int j = sub; j < nvec; j += G) {
+        float mq[V], sq[V], mp[V], sp[V];
+        load_vec<T, V>(mu_q + row * sq_mu + (int64_t)j * V, mq);
+        load_vec<T, V>(s_q + row * sq_s + (int64_t)j * V, sq);
+        if (mu_p) {
+          load_vec<T, V>(mu_p + row * sp_mu + (int64_t)j * V, mp);
+          load_vec<T, V>(s_p + row * sp_s + (int64_t)j * V, sp);
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          if (mu_p) {
+            // torch kl_normal_normal: var_ratio = (sq/sp)^2; t1 = ((mq-mp)/sp)^2
+            float r = sq[i] / sp[i];
+            float vr = r * r;
+            float d = (mq[i] - mp[i]) / sp[i];
+            klr += 0.5f * (vr + d * d - 1.0f - logf(vr));
+          } else {
+            float s2 = sq[i] * sq[i];
+            klr += 0.5f * (s2 + mq[i] * mq[i] - 1.0f - logf(s2));
+          }
+        }
+      }
+    }
+    klr = group_sum(klr, G);
+    if (row < B && sub == 0) kl[row] = from_f32<T>(klr);
+  }
+}
+
+// d kl / d (mu_q, s_q, mu_p, s_p), each written to a contiguous [B, L] buffer
+// (prior gradients skipped when g_mu_p is null).
+template <typename T, int V>
+__global__ __launch_bounds__(kBlock) void gauss_kl_bwd_kernel(
+    const T* __restrict__ mu_q, int64_t sq_mu, const T* __restrict__ s_q, int64_t sq_s, const T* __restrict__ mu_p,
+    int64_t sp_mu, const T* __restrict__ s_p, int64_t sp_s, const T* __restrict__ gkl, T* __restrict__ g_mu_q,
+    T* __restrict__ g_s_q, T* __restrict__ g_mu_p, T* __restrict__ g_s_p, int64_t B, int L, int G, int64_t tiles) {
+  const int rpb = kBlock / G;
+  const int sub = threadIdx.x % G;
+  const int rloc = threadIdx.x / G;
+  const int nvec = L / V;
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t row = t * rpb + rloc;
+    if (row >= B) continue;
+    const float gk = to_f32(gkl[row]);
+#pragma unroll 2
+    for (int j = sub; j < nvec; j += G) {
+      float mq[V], sq[V], mp[V], sp[V], o0[V], o1[V], o2[V], o3[V];
+      load_vec<T, V>(mu_q + row * sq_mu + (int64_t)j * V, mq);
+      load_vec<T, V>(s_q + row * sq_s + (int64_t)j * V, sq);
+      if (mu_p) {
+        load_vec<T, V>(mu_p + row * sp_mu + (int64_t)j * V, mp);
+        load_vec<T, V>(s_p + row * sp_s + (int64_t)j * V, sp);
+      }
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        if (mu_p) {
+          float ip = 1.0f / sp[i];
+          float ip2 = ip * ip;
+          float d = mq[i] - mp[i];
+          // kl = 0.5*(sq^2/sp^2 + d^2/sp^2 - 1 - log(sq^2) + log(sp^2))
+          o0[i] = gk * d * ip2;
+          o1[i] = gk * (sq[i] * ip2 - 1.0f / sq[i]);
+          o2[i] = -o0[i];
+          o3[i] = gk * (ip - (sq[i] * sq[i] + d * d) * ip2 * ip);
+        } else {
+          o0[i] = gk * mq[i];
+          o1[i] = gk * (sq[i] - 1.0f / sq[i]);
+        }
+      }
+      const int64_t o = row * L + (int64_t)j * V;
+      store_vec<T, V>(g_mu_q + o, o0);
+      store_vec<T, V>(g_s_q + o, o1);
+      if (mu_p && g_mu_p) {
+        store_vec<T, V>(g_mu_p + o, o2);
+        store_vec<T, V>(g_s_p + o, o3);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// finalize: out[k] = scale * sum_b partials[b*n + k]  (one block, fixed order)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void finalize_kernel(const float* __restrict__ partials, int nblocks, int n,
+                                                         float scale, float* __restrict__ out) {
+  __shared__ double lds[kBlock / 64];
+  for (int k = 0; k < n; ++k) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) s += (double)partials[(size_t)b * n + k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = 0.0;
+      for (int w = 0; w < kBlock / 64; ++w) tot += lds[w];
+      out[k] = (float)(tot * (double)scale);
+    }
+    __syncthreads();
+  }
+}
+
+void launch_finalize(const float* partials, int nblocks, int n, float scale, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, stream, partials, nblocks, n, scale, out);
+}
+
+template <typename T>
+static int gauss_fwd_dispatch(const void* logits, int64_t row_stride, const void* noise, void* z, void* s_out,
+                              void* kl, float* means, float* workspace, int64_t B, int64_t L, float eps_tol,
+                              float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0,
+                              hipStream_t stream) {
+  constexpr int VN = VecOf<T>::n;
+  const bool vec = (L % VN == 0) && (row_stride % VN == 0) && aligned16(logits) && (!z || aligned16(z)) &&
+                   (!noise || aligned16(noise)) && (!s_out || aligned16(s_out));
+  const RowGeom g = row_geom(B, vec ? L / VN : L);
+  if (vec) {
+    hipLaunchKernelGGL((gauss_fwd_kernel<T, VN>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)logits, row_stride,
+                       (const T*)noise, (T*)z, (T*)s_out, (T*)kl, workspace, B, (int)L, eps_tol, training, seed,
+                       offset, row0, g.G, g.tiles);
+  } else {
+    hipLaunchKernelGGL((gauss_fwd_kernel<T, 1>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)logits, row_stride,
+                       (const T*)noise, (T*)z, (T*)s_out, (T*)kl, workspace, B, (int)L, eps_tol, training, seed,
+                       offset, row0, g.G, g.tiles);
+  }
+  if (means) launch_finalize(workspace, g.grid, 2, mean_scale, means, stream);
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+template <typename T>
+static int gauss_bwd_dispatch(const void* logits, int64_t row_stride, const void* noise, const void* gz,
+                              const void* gs, const void* gkl, const float* gmeans, void* glogits, int64_t B,
+                              int64_t L, float eps_tol, float mean_scale, int training, uint64_t seed,
+                              uint64_t offset, int64_t row0, hipStream_t stream) {
+  constexpr int VN = VecOf<T>::n;
+  const bool vec = (L % VN == 0) && (row_stride % VN == 0) && aligned16(logits) && aligned16(glogits) &&
+                   (!noise || aligned16(noise)) && (!gz || aligned16(gz)) && (!gs || aligned16(gs));
+  const RowGeom g = row_geom(B, vec ? L / VN : L);
+  if (vec) {
+    hipLaunchKernelGGL((gauss_bwd_kernel<T, VN>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)logits, row_stride,
+                       (const T*)noise, (const T*)gz, (const T*)gs, (const T*)gkl, gmeans, (T*)glogits, B, (int)L,
+                       eps_tol, mean_scale, training, seed, offset, row0, g.G, g.tiles, 1);
+  } else {
+    hipLaunchKernelGGL((gauss_bwd_kernel<T, 1>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)logits, row_stride,
+                       (const T*)noise, (const T*)gz, (const T*)gs, (const T*)gkl, gmeans, (T*)glogits, B, (int)L,
+                       eps_tol, mean_scale, training, seed, offset, row0, g.G, g.tiles, 1);
+  }
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+template <typename T>
+static int gauss_kl_fwd_dispatch(const void* mu_q, int64_t sq_mu, const void* s_q, int64_t sq_s, const void* mu_p,
+                                 int64_t sp_mu, const void* s_p, int64_t sp_s, void* kl, int64_t B, int64_t L,
+                                 hipStream_t stream) {
+  constexpr int VN = VecOf<T>::n;
+  bool vec = (L % VN == 0) && (sq_mu % VN == 0) && (sq_s % VN == 0) && aligned16(mu_q) && aligned16(s_q);
+  if (mu_p) vec = vec && (sp_mu % VN == 0) && (sp_s % VN == 0) && aligned16(mu_p) && aligned16(s_p);
+  const RowGeom g = row_geom(B, vec ? L / VN : L);
+  if (vec) {
+    hipLaunchKernelGGL((gauss_kl_fwd_kernel<T, VN>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)mu_q, sq_mu,
+                       (const T*)s_q, sq_s, (const T*)mu_p, sp_mu, (const T*)s_p, sp_s, (T*)kl, B, (int)L, g.G,
+                       g.tiles);
+  } else {
+    hipLaunchKernelGGL((gauss_kl_fwd_kernel<T, 1>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)mu_q, sq_mu,
+                       (const T*)s_q, sq_s, (const T*)mu_p, sp_mu, (const T*)s_p, sp_s, (T*)kl, B, (int)L, g.G,
+                       g.tiles);
+  }
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+template <typename T>
+static int gauss_kl_bwd_dispatch(const void* mu_q, int64_t sq_mu, const void* s_q, int64_t sq_s, const void* mu_p,
+                                 int64_t sp_mu, const void* s_p, int64_t sp_s, const void* gkl, void* g_mu_q,
+                                 void* g_s_q, void* g_mu_p, void* g_s_p, int64_t B, int64_t L, hipStream_t stream) {
+  constexpr int VN = VecOf<T>::n;
+  bool vec = (L % VN == 0) && (sq_mu % VN == 0) && (sq_s % VN == 0) && aligned16(mu_q) && aligned16(s_q) &&
+             aligned16(g_mu_q) && aligned16(g_s_q);
+  if (mu_p) vec = vec && (sp_mu % VN == 0) && (sp_s % VN == 0) && aligned16(mu_p) && aligned16(s_p);
+  if (g_mu_p) vec = vec && aligned16(g_mu_p) && aligned16(g_s_p);
+  const RowGeom g = row_geom(B, vec ? L / VN : L);
+  if (vec) {
+    hipLaunchKernelGGL((gauss_kl_bwd_kernel<T, VN>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)mu_q, sq_mu,
+                       (const T*)s_q, sq_s, (const T*)mu_p, sp_mu, (const T*)s_p, sp_s, (const T*)gkl, (T*)g_mu_q,
+                       (T*)g_s_q, (T*)g_mu_p, (T*)g_s_p, B, (int)L, g.G, g.tiles);
+  } else {
+    hipLaunchKernelGGL((gauss_kl_bwd_kernel<T, 1>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)mu_q, sq_mu,
+                       (const T*)s_q, sq_s, (const T*)mu_p, sp_mu, (const T*)s_p, sp_s, (const T*)gkl, (T*)g_mu_q,
+                       (T*)g_s_q, (T*)g_mu_p, (T*)g_s_p, B, (int)L, g.G, g.tiles);
+  }
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+}  // namespace vae
+
+using namespace vae;
+
+extern "C" {
+
+int vae_gauss_reparam_kl_fwd(const void* logits, int64_t row_stride, const void* noise, void* z, void* s_out,
+                             void* kl, float* means, float* workspace, int64_t B, int64_t L, float eps_tol,
+                             float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0, int dtype,
+                             vae_stream_t stream) {
+  if (!logits || (!z && training) || !kl || !workspace || B < 0 || L <= 0 || L > VAE_MAX_ROW || row_stride < 2 * L)
+    return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VAE_F32)
+    return gauss_fwd_dispatch<float>(logits, row_stride, noise, z, s_out, kl, means, workspace, B, L, eps_tol,
+                                     mean_scale, training, seed, offset, row0, st);
+  if (dtype == VAE_BF16)
+    return gauss_fwd_dispatch<bf16_t>(logits, row_stride, noise, z, s_out, kl, means, workspace, B, L, eps_tol,
+                                      mean_scale, training, seed, offset, row0, st);
+  return VAE_ERR_ARG;
+}
+
+int vae_gauss_reparam_kl_bwd(const void* logits, int64_t row_stride, const void* noise, const void* gz,
+                             const void* gs, const void* gkl, const float* gmeans, void* glogits, int64_t B,
+                             int64_t L, float eps_tol, float mean_scale, int training, uint64_t seed,
+                             uint64_t offset, int64_t row0, int dtype, vae_stream_t stream) {
+  if (!logits || !glogits || B < 0 || L <= 0 || L > VAE_MAX_ROW || row_stride < 2 * L) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VAE_F32)
+    return gauss_bwd_dispatch<float>(logits, row_stride, noise, gz, gs, gkl, gmeans, glogits, B, L, eps_tol,
+                                     mean_scale, training, seed, offset, row0, st);
+  if (dtype == VAE_BF16)
+    return gauss_bwd_dispatch<bf16_t>(logits, row_stride, noise, gz, gs, gkl, gmeans, glogits, B, L, eps_tol,
+                                      mean_scale, training, seed, offset, row0, st);
+  return VAE_ERR_ARG;
+}
+
+int vae_gauss_kl_fwd(const void* mu_q, int64_t stride_mu_q, const void* s_q, int64_t stride_s_q, const void* mu_p,
+                     int64_t stride_mu_p, const void* s_p, int64_t stride_s_p, void* kl, int64_t B, int64_t L,
+                     int dtype, vae_stream_t stream) {
+  if (!mu_q || !s_q || !kl || B < 0 || L <= 0 || L > VAE_MAX_ROW || ((mu_p == nullptr) != (s_p == nullptr)))
+    return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VAE_F32)
+    return gauss_kl_fwd_dispatch<float>(mu_q, stride_mu_q, s_q, stride_s_q, mu_p, stride_mu_p, s_p, stride_s_p, kl,
+                                        B, L, st);
+  if (dtype == VAE_BF16)
+    return gauss_kl_fwd_dispatch<bf16_t>(mu_q, stride_mu_q, s_q, stride_s_q, mu_p, stride_mu_p, s_p, stride_s_p, kl,
+                                         B, L, st);
+  return VAE_ERR_ARG;
+}
+
+int vae_gauss_kl_bwd(const void* mu_q, int64_t stride_mu_q, const void* s_q, int64_t stride_s_q, const void* mu_p,
+                     int64_t stride_mu_p, const void* s_p, int64_t stride_s_p, const void* gkl, void* g_mu_q,
+                     void* g_s_q, void* g_mu_p, void* g_s_p, int64_t B, int64_t L, int dtype, vae_stream_t stream) {
+  if (!mu_q || !s_q || !gkl || !g_mu_q || !g_s_q || B < 0 || L <= 0 || L > VAE_MAX_ROW ||
+      ((mu_p == nullptr) != (s_p == nullptr)) || ((g_mu_p == nullptr) != (g_s_p == nullptr)) || (g_mu_p && !mu_p))
+    return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VAE_F32)
+    return gauss_kl_bwd_dispatch<float>(mu_q, stride_mu_q, s_q, stride_s_q, mu_p, stride_mu_p, s_p, stride_s_p, gkl,
+                                        g_mu_q, g_s_q, g_mu_p, g_s_p, B, L, st);
+  if (dtype == VAE_BF16)
+    return gauss_kl_bwd_dispatch<bf16_t>(mu_q, stride_mu_q, s_q, stride_s_q, mu_p, stride_mu_p, s_p, stride_s_p,
+                                         gkl, g_mu_q, g_s_q, g_mu_p, g_s_p, B, L, st);
+  return VAE_ERR_ARG;
+}
+
+}  // extern "C"
