@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""ELBO-step throughput of the hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): simple_vae, IsotropicGaussian latent 512, B = 65536 samples
+per GPU, 1x28x28 Bernoulli NLL, fp32, synthetic inputs resident in HBM.  One step = one pass of
+the hot path over one batch, forward and backward:
+
+    gauss_reparam_kl_fwd -> nll_elbo_fwd -> [N>1: one packed all-reduce of the 8 batch scalars]
+    -> nll_elbo_bwd -> gauss_reparam_kl_bwd
+
+The encoder/decoder networks are not part of the path (stock PyTorch in the reference's host
+project); their outputs (encoder logits, decoder logits) and the decoder's gradient w.r.t. z are
+synthetic tensors.  Every kernel goes through the C ABI (libvae_amd.so); HIP events around every
+launch of the timed steps give the per-kernel durations behind `roofline`.
+
+The batch shards by rows with no data-path collective except the scalar all-reduce (weak scaling:
+per-GPU batch fixed).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+B_PER_GPU, L, C, H, W = 65536, 512, 1, 28, 28
+D = C * H * W
+
+
+def algorithmic_bytes(B):
+    """SURVEY 8(d), fp32, per launch."""
+    return {
+        'gauss_reparam_kl_fwd': (16 * L + 4) * B,   # logits 8L + noise 4L + z 4L + kl 4
+        'gauss_reparam_kl_bwd': (24 * L + 4) * B,   # logits 8L + noise 4L + gz 4L + gkl 4 + glogits 8L
+        'nll_elbo_fwd': (8 * D + 12) * B,           # x 4D + recon 4D + kld 4 + loss, elbo 8
+        'nll_elbo_bwd': (12 * D) * B,               # x 4D + recon 4D + grecon 4D
+    }
+
+
+def cpu_baseline(seconds=12.0):
+    """The oracle's unfused op sequence (the reference's CPU path restated) on the host cores."""
+    from oracle import cpu_ref as O
+    threads = torch.get_num_threads()
+    Bc = 4096
+    g = torch.Generator().manual_seed(1234)
+    logits = torch.randn(Bc, 2 * L, generator=g)
+    noise = torch.randn(Bc, L, generator=g)
+    x = (torch.rand(Bc, C, H, W, generator=g) < 0.13).float()
+    recon = torch.randn(Bc, C, H, W, generator=g)
+    O.elbo_step(logits, noise, x, recon)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.elbo_step(logits, noise, x, recon)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds:
+            break
+    return {'value': Bc * n / dt, 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d fwd+bwd ELBO steps of B=%d, L=%d, 1x28x28 Bernoulli, fp32, oracle/cpu_ref.elbo_step '
+                      '(torch CPU ops in the reference op order), %.1f s' % (n, Bc, L, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=B_PER_GPU, help='samples per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from vae_amd import _lib
+    from vae_amd._lib import call, ptr
+    _lib.load()
+
+    B = args.batch
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    f32 = dict(dtype=torch.float32, device=dev)
+    logits = torch.randn(B, 2 * L, generator=gen, **f32)
+    noise = torch.randn(B, L, generator=gen, **f32)
+    x = (torch.rand(B, D, generator=gen, **f32) < 0.13).float()
+    recon = torch.randn(B, D, generator=gen, **f32)
+    gz = torch.randn(B, L, generator=gen, **f32) * (1.0 / B)   # the decoder's d loss / d z (synthetic)
+    # outputs, allocated once
+    z = torch.empty(B, L, **f32)
+    logvar = torch.empty(B, L, **f32)
+    kl = torch.empty(B, **f32)
+    nll = torch.empty(B, **f32)
+    loss = torch.empty(B, **f32)
+    elbo = torch.empty(B, **f32)
+    scalars = torch.zeros(8, **f32)          # 6 ELBO means + mu_mean, logvar_mean: one packed message
+    gmeans = torch.zeros(6, **f32)
+    gmeans[0] = 1.0                           # d(loss_mean) = 1: what loss_mean.backward() seeds
+    grecon = torch.empty(B, D, **f32)
+    gkld = torch.empty(B, **f32)
+    glogits = torch.empty(B, 2 * L, **f32)
+    ws = _lib.workspace(dev)
+    st = _lib.stream_ptr(dev)
+    inv_count = 1.0 / (B * world)
+    mean_scale = 1.0 / (B * world * L)
+    row0 = rank * B
+
+    names = ['gauss_reparam_kl_fwd', 'nll_elbo_fwd', 'nll_elbo_bwd', 'gauss_reparam_kl_bwd']
+    pmeans = ctypes_off(scalars, 6)
+
+    def step(ev=None):
+        def mark(i):
+            if ev is not None:
+                ev[i].record()
+        mark(0)
+        call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, ptr(noise), ptr(z), ptr(logvar), ptr(kl), pmeans,
+             ptr(ws), B, L, 1e-6, mean_scale, 1, 0, 0, row0, 0, st)
+        mark(1)
+        call('vae_nll_elbo_fwd', ptr(x), ptr(recon), 0, ptr(kl), None, None, 1.0, inv_count, ptr(nll), ptr(loss),
+             ptr(elbo), ptr(scalars), ptr(ws), B, D, 0, st)
+        mark(2)
+        if dist is not None:
+            dist.all_reduce(scalars)          # global-batch means (abstract_vae.py:381-387) in one message
+        mark(3)
+        call('vae_nll_elbo_bwd', ptr(x), ptr(recon), 0, None, None, None, ptr(gmeans), 1.0, inv_count, ptr(grecon),
+             ptr(gkld), None, None, B, D, 0, st)
+        mark(4)
+        call('vae_gauss_reparam_kl_bwd', ptr(logits), 2 * L, ptr(noise), ptr(gz), None, ptr(gkld), None,
+             ptr(glogits), B, L, 1e-6, mean_scale, 1, 0, 0, row0, 0, st)
+        mark(5)
+
+    for _ in range(args.warmup):
+        step()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel average durations from the HIP events recorded on the launch stream during the timed steps
+    seg = {'gauss_reparam_kl_fwd': (0, 1), 'nll_elbo_fwd': (1, 2), 'nll_elbo_bwd': (3, 4),
+           'gauss_reparam_kl_bwd': (4, 5)}
+    dur_ms = {n: sum(e[a].elapsed_time(e[b]) for e in events) / args.steps for n, (a, b) in seg.items()}
+    sanity = float(scalars[0].item())
+    if not (sanity == sanity):
+        raise SystemExit('bench: loss_mean is NaN')
+
+    if rank == 0:
+        ab = algorithmic_bytes(B)
+        kernels = {}
+        for n in names:
+            gbs = ab[n] / (dur_ms[n] * 1e-3) / 1e9
+            kernels[n] = {'avg_ms': round(dur_ms[n], 5), 'algorithmic_bytes': ab[n], 'achieved_GBs': round(gbs, 1),
+                          'frac': round(gbs / HBM_PEAK_GBS, 4)}
+        dom = max(names, key=lambda n: dur_ms[n])
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        total_bytes = sum(ab.values())
+        ksum = sum(dur_ms.values())
+        out = {
+            'metric': 'ELBO-step samples/sec', 'value': B * world * args.steps / dt, 'unit': 'samples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: simple_vae IsotropicGaussian latent 512, B=%d per GPU, 1x28x28 '
+                                   'Bernoulli NLL; step = reparam+KL fwd, NLL+ELBO fwd, both backward' % B,
+                       'global_batch': B * world, 'latent': L, 'pixels': D, 'parallelism': 'dp%d' % world,
+                       'noise': 'injected (resident in HBM)'},
+            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': kernels[dom]['achieved_GBs'],
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kernels[dom]['frac'], 'traffic': traffic},
+            'kernels': kernels,
+            'hot_path': {'algorithmic_bytes_per_step': total_bytes, 'kernel_ms_per_step': round(ksum, 5),
+                         'achieved_GBs': round(total_bytes / (ksum * 1e-3) / 1e9, 1),
+                         'frac': round(total_bytes / (ksum * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            'loss_mean': sanity,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def ctypes_off(t, n):
+    """Device pointer n elements into tensor t."""
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr() + n * t.element_size())
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,169 @@
+"""GPU parity: fused NLL + ELBO kernels vs the oracle (NLL definitions: parity unpinned by the
+reference, helpers is un-vendored; the ELBO combine is pinned by tests/golden/elbo.pt)."""
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def close(a, b, rtol=1e-5, atol=1e-5):
+    torch.testing.assert_close(a.detach().float().cpu(), b.detach().float().cpu(), rtol=rtol, atol=atol)
+
+
+def close_cond(a, ref32, ref64, rtol=1e-5, atol=1e-6):
+    """fp32 parity for a function that is ill-conditioned in fp32 (the discretized logistic subtracts
+    two sigmoids and divides by the difference): elementwise rtol is meaningless where the fp32
+    reference itself is far from the true value, so the kernel is required to be (about) as accurate
+    against an fp64 evaluation as the fp32 oracle is: L2 and max error within 2x the oracle's, plus
+    rtol/atol of the fp64 value."""
+    a = a.detach().double().cpu()
+    ref32, ref64 = ref32.detach().double(), ref64.detach().double()
+    e_k, e_o = (a - ref64), (ref32 - ref64)
+    assert float(e_k.norm()) <= 2 * float(e_o.norm()) + rtol * float(ref64.norm()) + atol, \
+        'L2 error %g vs oracle %g' % (float(e_k.norm()), float(e_o.norm()))
+    assert float(e_k.abs().max()) <= 2 * float(e_o.abs().max()) + rtol * float(ref64.abs().max()) + atol, \
+        'max error %g vs oracle %g' % (float(e_k.abs().max()), float(e_o.abs().max()))
+
+
+def images(B, C, H, W, nll_type):
+    if nll_type == 'bernoulli':
+        x = (torch.rand(B, C, H, W) < 0.13).float()
+        recon = torch.randn(B, C, H, W) * 2
+    else:
+        x = torch.floor(torch.rand(B, C, H, W) * 256) / 255.0
+        x = x.clamp(0, 1)
+        recon = torch.cat([torch.randn(B, C, H, W), torch.randn(B, C, H, W) * 3 - 1.5], 1)
+    return x, recon
+
+
+@pytest.mark.parametrize('nll_type', ['bernoulli', 'gaussian', 'disc_logistic'])
+@pytest.mark.parametrize('shape', [(1, 1, 1, 1), (5, 1, 28, 28), (64, 3, 5, 5), (300, 1, 28, 28), (3, 3, 64, 64),
+                                   (17, 3, 64, 64)])
+def test_nll_elbo_vs_oracle(nll_type, shape):
+    from vae_amd import elbo as E
+    torch.manual_seed(sum(shape))
+    B = shape[0]
+    x, recon = images(*shape, nll_type)
+    kld = torch.rand(B) * 10
+    extra = {'a': torch.rand(B), 'b': torch.rand(B)}
+    mi = torch.rand(B)
+    beta = 0.7
+    w = torch.randn(B)
+
+    rc = recon.clone().requires_grad_(True)
+    kc = kld.clone().requires_grad_(True)
+    n0 = O.nll(x, rc, nll_type)
+    r0 = O.loss_function(n0, kc, beta, mut_info=mi, extra=extra)
+    obj0 = (r0['loss'] * w).sum() + (r0['elbo'] * w).sum() * 0.5 + r0['loss_mean'] + 2 * r0['nll_mean'] \
+        + 3 * r0['kld_mean'] + r0['elbo_mean']
+    g0r, g0k = torch.autograd.grad(obj0, [rc, kc])
+    # the same in fp64, to bound the fp32 oracle's own conditioning error
+    rc64 = recon.double().requires_grad_(True)
+    n64 = O.nll(x.double(), rc64, nll_type)
+    r64 = O.loss_function(n64, kld.double(), beta, mut_info=mi.double(), extra={k: v.double() for k, v in extra.items()})
+    obj64 = (r64['loss'] * w.double()).sum() + (r64['elbo'] * w.double()).sum() * 0.5 + r64['loss_mean'] \
+        + 2 * r64['nll_mean'] + 3 * r64['kld_mean'] + r64['elbo_mean']
+    (g64r,) = torch.autograd.grad(obj64, [rc64])
+
+    rd = recon.to(DEV).requires_grad_(True)
+    kd = kld.to(DEV).requires_grad_(True)
+    r1 = E.loss_function(rd, x.to(DEV), kd, nll_type, kl_beta=beta, mut_info=mi.to(DEV),
+                         extra_loss_terms={k: v.to(DEV) for k, v in extra.items()})
+    assert set(r1) == set(r0)
+    wd = w.to(DEV)
+    obj1 = (r1['loss'] * wd).sum() + (r1['elbo'] * wd).sum() * 0.5 + r1['loss_mean'] + 2 * r1['nll_mean'] \
+        + 3 * r1['kld_mean'] + r1['elbo_mean']
+    g1r, g1k = torch.autograd.grad(obj1, [rd, kd])
+    D = x[0].numel()
+    for k in r0:
+        if torch.is_tensor(r0[k]):
+            close(r1[k], r0[k], rtol=1e-5, atol=1e-6 * D)
+        else:
+            assert r1[k] == r0[k]
+    close(E.nll(x.to(DEV), rd, nll_type), n0, rtol=1e-5, atol=1e-6 * D)
+    if nll_type == 'disc_logistic':
+        close_cond(g1r, g0r, g64r)
+    else:
+        close(g1r, g0r, rtol=1e-5, atol=2e-6)
+    close(g1k, g0k, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('name', ['elbo_beta1_plain', 'elbo_beta0.25_extra'])
+def test_combine_golden(golden, name):
+    from vae_amd import elbo as E
+    g = golden('elbo')[name]
+    res = E.loss_function(None, None, g['kld'].to(DEV), 'bernoulli', kl_beta=g['kl_beta'],
+                          extra_loss_terms={k: v.to(DEV) for k, v in g['extra'].items()},
+                          nll_given=g['nll'].to(DEV))
+    assert set(res) == set(g['result'])
+    for k, v in g['result'].items():
+        if torch.is_tensor(v):
+            close(res[k], v, rtol=1e-6, atol=1e-5)
+        else:
+            assert res[k] == v
+
+
+def test_combine_backward():
+    from vae_amd import functional as F_
+    torch.manual_seed(0)
+    B = 1000
+    n, k, a, m = [torch.rand(B).requires_grad_(True) for _ in range(4)]
+    w = torch.randn(B)
+    r0 = O.loss_function(n, k, 0.3, mut_info=m, extra={'a': a})
+    g0 = torch.autograd.grad((r0['loss'] * w).sum() + r0['elbo_mean'] + r0['mut_info_mean'], [n, k, a, m])
+    nd, kd, ad, md = [t.detach().to(DEV).requires_grad_(True) for t in (n, k, a, m)]
+    loss, elbo, means = F_.elbo_combine(nd, kd, ad, md, kl_beta=0.3)
+    g1 = torch.autograd.grad((loss * w.to(DEV)).sum() + means[1] + means[5], [nd, kd, ad, md])
+    for x, y in zip(g1, g0):
+        close(x, y)
+
+
+def test_mixin_K_samples():
+    """abstract_vae.py:347-354: K > 1 averages K decodes' NLL in training."""
+    from vae_amd.elbo import ELBOMixin
+    from vae_amd.reparameterizers import IsotropicGaussian
+    torch.manual_seed(4)
+    B, L = 16, 8
+
+    class Model(torch.nn.Module, ELBOMixin):
+        def __init__(self):
+            super().__init__()
+            self.config = {'continuous_size': 2 * L, 'nll_type': 'bernoulli', 'kl_beta': 1.0, 'cuda': True,
+                           'half': False}
+            self.reparameterizer = IsotropicGaussian(self.config)
+            self.dec = torch.nn.Linear(L, 784)
+
+        def decode(self, z):
+            return self.dec(z).view(-1, 1, 28, 28)
+
+    m = Model().to(DEV)
+    m.train()
+    logits = torch.randn(B, 2 * L, device=DEV)
+    x = (torch.rand(B, 1, 28, 28, device=DEV) < 0.2).float()
+    z, params = m.reparameterize(logits)
+    out = m.loss_function(m.decode(z), x, params, K=3)
+    assert out['loss'].shape == (B,) and torch.isfinite(out['loss_mean'])
+    out['loss_mean'].backward()
+    assert m.dec.weight.grad is not None
+    # K = 1 equals the plain fused path against the oracle
+    m.eval()
+    z, params = m.reparameterize(logits)
+    recon = m.decode(z)
+    out = m.loss_function(recon, x, params)
+    ref = O.loss_function(O.nll(x.cpu(), recon.detach().cpu(), 'bernoulli'),
+                          O.gauss_kl(O.gauss_forward(logits.cpu(), None, training=False)[1]))
+    close(out['loss'], ref['loss'], rtol=1e-5, atol=1e-3)
+    close(out['elbo_mean'], ref['elbo_mean'], rtol=1e-5, atol=1e-3)
+
+
+def test_bf16_nll():
+    torch.manual_seed(5)
+    x, recon = images(32, 1, 28, 28, 'bernoulli')
+    from vae_amd import elbo as E
+    n1 = E.nll(x.to(DEV).bfloat16(), recon.to(DEV).bfloat16(), 'bernoulli')
+    n0 = O.nll(x, recon.bfloat16().float(), 'bernoulli')
+    assert n1.dtype == torch.bfloat16
+    close(n1, n0, rtol=1e-2, atol=1.0)

@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (must be imported before the CDLL below, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libvae_amd.so')
+LIB_PATH = os.environ.get('VAE_AMD_LIB') or os.path.join(_HERE, 'libvae_amd.so')  # env override: tuning builds only
 ABI_VERSION = 1
 
 VAE_OK, VAE_ERR_ARG, VAE_ERR_LAUNCH = 0, 1, 2

@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace vae {
 
@@ -39,10 +40,35 @@ __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) {
   return r;
 }
 
-// 16-byte packets: the widest per-lane access (global_load/store_dwordx4).
+// Individually rounded ops.  hipcc's default -ffp-contract=fast turns a*b+c into one fma
+// (and HIP's __fmul_rn/__fadd_rn are plain operators, so they fuse too); where the
+// reference's op sequence must be reproduced bit for bit (z, logvar, the Gumbel logits)
+// the product and the sum have to round separately, as two torch ops do.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float div_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a / b;
+}
+
+// 16-byte packets: the widest per-lane access (global_load/store_dwordx4).  Every tensor on
+// this path is streamed exactly once per kernel, so loads and stores carry the non-temporal
+// hint (no reuse to keep in L2 / Infinity Cache).
 template <typename T, int V>
-struct alignas(sizeof(T) * V) Pack {
-  T v[V];
+struct PackOf;
+template <>
+struct PackOf<float, 4> {
+  typedef float type __attribute__((ext_vector_type(4)));
+};
+template <>
+struct PackOf<bf16_t, 8> {
+  typedef uint32_t type __attribute__((ext_vector_type(4)));
 };
 
 template <typename T>
@@ -50,14 +76,34 @@ struct VecOf {
   static constexpr int n = 16 / sizeof(T);
 };
 
+#ifndef VAE_NT_LOAD
+#define VAE_NT_LOAD 1
+#endif
+#ifndef VAE_NT_STORE
+#define VAE_NT_STORE 1
+#endif
+
 template <typename T, int V>
 __device__ __forceinline__ void load_vec(const T* __restrict__ p, float (&out)[V]) {
   if constexpr (V == 1) {
     out[0] = to_f32(p[0]);
   } else {
-    Pack<T, V> raw = *reinterpret_cast<const Pack<T, V>*>(p);
+    typedef typename PackOf<T, V>::type P;
+#if VAE_NT_LOAD
+    const P raw = __builtin_nontemporal_load(reinterpret_cast<const P*>(p));
+#else
+    const P raw = *reinterpret_cast<const P*>(p);
+#endif
+    if constexpr (sizeof(T) == 4) {
 #pragma unroll
-    for (int i = 0; i < V; ++i) out[i] = to_f32(raw.v[i]);
+      for (int i = 0; i < V; ++i) out[i] = raw[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < V / 2; ++i) {
+        out[2 * i] = __uint_as_float(raw[i] << 16);
+        out[2 * i + 1] = __uint_as_float(raw[i] & 0xffff0000u);
+      }
+    }
   }
 }
 
@@ -66,11 +112,46 @@ __device__ __forceinline__ void store_vec(T* __restrict__ p, const float (&in)[V
   if constexpr (V == 1) {
     p[0] = from_f32<T>(in[0]);
   } else {
-    Pack<T, V> raw;
+    typedef typename PackOf<T, V>::type P;
+    P raw;
+    if constexpr (sizeof(T) == 4) {
 #pragma unroll
-    for (int i = 0; i < V; ++i) raw.v[i] = from_f32<T>(in[i]);
-    *reinterpret_cast<Pack<T, V>*>(p) = raw;
+      for (int i = 0; i < V; ++i) raw[i] = in[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < V / 2; ++i)
+        raw[i] = (uint32_t)from_f32<T>(in[2 * i]).bits | ((uint32_t)from_f32<T>(in[2 * i + 1]).bits << 16);
+    }
+#if VAE_NT_STORE
+    __builtin_nontemporal_store(raw, reinterpret_cast<P*>(p));
+#else
+    *reinterpret_cast<P*>(p) = raw;
+#endif
   }
+}
+
+// U row-chunks of one lane, all loads issued before any use: lane `sub` of a G-lane group owns
+// vectors j0, j0+G, ... of the row.  Indices past the row end are clamped to the last vector
+// (always a valid address, an L1 hit, masked by the caller with `j < nvec`), so the loads carry
+// no branch and the compiler batches them under one counted s_waitcnt: 16*U bytes per tensor
+// in flight per lane, which is what keeps HBM busy at 8 waves/SIMD.
+template <typename T, int V, int U>
+__device__ __forceinline__ void load_chunk(const T* __restrict__ base, int j0, int G, int nvec, float (&out)[U][V]) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    int j = j0 + u * G;
+    j = j < nvec ? j : nvec - 1;
+    load_vec<T, V>(base + (int64_t)j * V, out[u]);
+  }
+}
+
+// cheap transcendental forms (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1-2 ulp): used where the
+// result feeds a row sum or a gradient whose tolerance is rtol 1e-5, never where a value has
+// to match the reference bit for bit.
+__device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+// log(1 + e) for e in [0, 1]
+__device__ __forceinline__ float log1p_unit(float e) {
+  return e < 1e-3f ? e * (1.0f - e * (0.5f - e * (1.0f / 3.0f))) : __logf(1.0f + e);
 }
 
 // Sum / max over the G lanes that share a row (G power of two, <= 64).  After the
@@ -185,22 +266,50 @@ __device__ __forceinline__ void philox_uniform(uint64_t seed, uint64_t stream, u
 // ---- host-side launch geometry -------------------------------------------------
 struct RowGeom {
   int G;               // lanes per row
+  int U;               // row-chunks loaded up front per lane (1, 2 or 4)
   int rows_per_block;  // kBlock / G
   int64_t tiles;       // ceil(rows / rows_per_block)
   int grid;            // min(tiles, kMaxGrid)
 };
 
+// Pick lanes-per-row: the G (8..64) that wastes the fewest lane slots over whole U=4 passes,
+// larger G on ties (longer contiguous runs per load instruction).  Short rows get the smallest
+// power of two that covers them.  VAE_AMD_G overrides (tuning only).
 inline RowGeom row_geom(int64_t rows, int64_t vecs_per_row) {
   RowGeom g;
   int G = 1;
-  while (G < 64 && G < vecs_per_row) G <<= 1;
+  if (vecs_per_row <= 64) {
+    while (G < vecs_per_row) G <<= 1;
+  } else {
+    double best = -1.0;
+    for (int c = 64; c >= 8; c >>= 1) {
+      const int64_t span = (int64_t)c * 4;
+      const int64_t slots = (vecs_per_row + span - 1) / span * span;
+      const double eff = (double)vecs_per_row / (double)slots;
+      if (eff > best + 0.02) { best = eff; G = c; }
+    }
+  }
+  if (const char* e = getenv("VAE_AMD_G")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) G = v;
+  }
   g.G = G;
+  const int64_t iters = (vecs_per_row + G - 1) / G;
+  g.U = iters >= 3 ? 4 : (iters == 2 ? 2 : 1);
   g.rows_per_block = kBlock / G;
   g.tiles = (rows + g.rows_per_block - 1) / g.rows_per_block;
   g.grid = (int)(g.tiles < kMaxGrid ? g.tiles : kMaxGrid);
   if (g.grid < 1) g.grid = 1;
   return g;
 }
+
+// Instantiate `...` with a constexpr U matching the runtime geometry.
+#define VAE_SWITCH_U(u_, ...)                   \
+  switch (u_) {                                 \
+    case 1: { constexpr int U = 1; __VA_ARGS__; } break; \
+    case 2: { constexpr int U = 2; __VA_ARGS__; } break; \
+    default: { constexpr int U = 4; __VA_ARGS__; } break; \
+  }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -22,7 +22,10 @@ namespace vae {
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 constexpr float kBin = 1.0f / 256.0f;
 
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+__device__ __forceinline__ float sigmoidf_(float v) { return fast_rcp(1.0f + expf(-v)); }
+// correctly divided form for the discretized logistic, whose sigmoids are subtracted from each
+// other and from 1 (an ulp there is amplified by 1/P)
+__device__ __forceinline__ float sigmoid_acc(float v) { return 1.0f / (1.0f + expf(-v)); }
 __device__ __forceinline__ float softplusf_(float v) {
   // torch.nn.functional.softplus: linear above threshold 20
   return v > 20.0f ? v : log1pf(expf(v));
@@ -31,7 +34,7 @@ __device__ __forceinline__ float softplusf_(float v) {
 // ---- the three NLLs: value and d/d(recon) per element --------------------------
 // NLL == VAE_NLL_BERNOULLI: -Bernoulli(logits=l).log_prob(x) = max(l,0) - l*x + log1p(exp(-|l|))
 __device__ __forceinline__ float nll_bern(float x, float l) {
-  return fmaxf(l, 0.0f) - l * x + log1pf(expf(-fabsf(l)));
+  return fmaxf(l, 0.0f) - l * x + log1p_unit(expf(-fabsf(l)));
 }
 __device__ __forceinline__ float nll_bern_grad(float x, float l) { return sigmoidf_(l) - x; }
 
@@ -54,24 +57,24 @@ __device__ __forceinline__ void nll_gauss_grad(float x, float m, float v, float&
 // -log(sigmoid(t + bin/sc) - sigmoid(t) + 1e-7)
 __device__ __forceinline__ float nll_dlog(float x, float a, float v) {
   float xq = floorf(x / kBin) * kBin;
-  float m = sigmoidf_(a);
+  float m = sigmoid_acc(a);
   float lv = fminf(fmaxf(v, -4.5f), 0.0f);
   float sc = expf(lv);
   float t = (xq - m) / sc;
-  float cp = sigmoidf_(t + kBin / sc);
-  float cm = sigmoidf_(t);
+  float cp = sigmoid_acc(t + kBin / sc);
+  float cm = sigmoid_acc(t);
   return -logf(cp - cm + 1e-7f);
 }
 __device__ __forceinline__ void nll_dlog_grad(float x, float a, float v, float& ga, float& gv) {
   float xq = floorf(x / kBin) * kBin;
-  float m = sigmoidf_(a);
+  float m = sigmoid_acc(a);
   float lv = fminf(fmaxf(v, -4.5f), 0.0f);
   float sc = expf(lv);
   float isc = 1.0f / sc;
   float t = (xq - m) * isc;
   float tp = t + kBin * isc;
-  float cp = sigmoidf_(tp);
-  float cm = sigmoidf_(t);
+  float cp = sigmoid_acc(tp);
+  float cm = sigmoid_acc(t);
   float ip = 1.0f / (cp - cm + 1e-7f);
   float dp = -cp * (1.0f - cp) * ip;  // d nll / d tp
   float dm = cm * (1.0f - cm) * ip;   // d nll / d t
@@ -98,7 +101,7 @@ __device__ __forceinline__ float row_sum(float v, int G) {
 // ---------------------------------------------------------------------------
 // forward: nll[B] (+ loss[B], elbo[B], block partials of the six sums)
 // ---------------------------------------------------------------------------
-template <typename T, int V, int NLL>
+template <typename T, int V, int NLL, int U>
 __global__ __launch_bounds__(kBlock) void nll_elbo_fwd_kernel(
     const T* __restrict__ x, const T* __restrict__ recon, const T* __restrict__ kld, const T* __restrict__ add,
     const T* __restrict__ mi, T* __restrict__ nll_out, T* __restrict__ loss, T* __restrict__ elbo,
@@ -116,17 +119,21 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_fwd_kernel(
     if (row < B) {
       const T* xr = x + row * D;
       const T* rr = recon + row * rstride;
-#pragma unroll 4
-      for (int j = sub; j < nvec; j += G) {
-        float xv[V], a[V], b[V];
-        load_vec<T, V>(xr + (int64_t)j * V, xv);
-        load_vec<T, V>(rr + (int64_t)j * V, a);
-        if constexpr (NLL != VAE_NLL_BERNOULLI) load_vec<T, V>(rr + D + (int64_t)j * V, b);
+      for (int j0 = sub; j0 < nvec; j0 += G * U) {
+        float xv[U][V], a[U][V], b[U][V];
+        load_chunk<T, V, U>(xr, j0, G, nvec, xv);
+        load_chunk<T, V, U>(rr, j0, G, nvec, a);
+        if constexpr (NLL != VAE_NLL_BERNOULLI) load_chunk<T, V, U>(rr + D, j0, G, nvec, b);
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-          if constexpr (NLL == VAE_NLL_BERNOULLI) s += nll_bern(xv[i], a[i]);
-          if constexpr (NLL == VAE_NLL_GAUSSIAN) s += nll_gauss(xv[i], a[i], b[i]);
-          if constexpr (NLL == VAE_NLL_DISC_LOGISTIC) s += nll_dlog(xv[i], a[i], b[i]);
+        for (int u = 0; u < U; ++u) {
+          float su = 0.f;
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            if constexpr (NLL == VAE_NLL_BERNOULLI) su += nll_bern(xv[u][i], a[u][i]);
+            if constexpr (NLL == VAE_NLL_GAUSSIAN) su += nll_gauss(xv[u][i], a[u][i], b[u][i]);
+            if constexpr (NLL == VAE_NLL_DISC_LOGISTIC) su += nll_dlog(xv[u][i], a[u][i], b[u][i]);
+          }
+          s += (j0 + u * G < nvec) ? su : 0.f;
         }
       }
     }
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_fwd_kernel(
 // backward: d recon (and the [B]-sized d kld / d add / d mi)
 //   c_nll[b] = gnll[b] + gloss[b] + gelbo[b] + (gm_loss + gm_elbo + gm_nll) * inv_count
 // ---------------------------------------------------------------------------
-template <typename T, int V, int NLL>
+template <typename T, int V, int NLL, int U>
 __global__ __launch_bounds__(kBlock) void nll_elbo_bwd_kernel(
     const T* __restrict__ x, const T* __restrict__ recon, const T* __restrict__ gnll, const T* __restrict__ gloss,
     const T* __restrict__ gelbo, const float* __restrict__ gmeans, T* __restrict__ grecon, T* __restrict__ gkld,
@@ -183,26 +190,32 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_bwd_kernel(
     const T* xr = x + row * D;
     const T* rr = recon + row * rstride;
     T* gr = grecon + row * rstride;
-#pragma unroll 4
-    for (int j = sub; j < nvec; j += G) {
-      float xv[V], a[V], b[V], ga[V], gb[V];
-      load_vec<T, V>(xr + (int64_t)j * V, xv);
-      load_vec<T, V>(rr + (int64_t)j * V, a);
-      if constexpr (NLL != VAE_NLL_BERNOULLI) load_vec<T, V>(rr + D + (int64_t)j * V, b);
+    for (int j0 = sub; j0 < nvec; j0 += G * U) {
+      float xv[U][V], a[U][V], b[U][V];
+      load_chunk<T, V, U>(xr, j0, G, nvec, xv);
+      load_chunk<T, V, U>(rr, j0, G, nvec, a);
+      if constexpr (NLL != VAE_NLL_BERNOULLI) load_chunk<T, V, U>(rr + D, j0, G, nvec, b);
 #pragma unroll
-      for (int i = 0; i < V; ++i) {
-        if constexpr (NLL == VAE_NLL_BERNOULLI) ga[i] = c * nll_bern_grad(xv[i], a[i]);
-        if constexpr (NLL == VAE_NLL_GAUSSIAN) {
-          nll_gauss_grad(xv[i], a[i], b[i], ga[i], gb[i]);
-          ga[i] *= c; gb[i] *= c;
-        }
-        if constexpr (NLL == VAE_NLL_DISC_LOGISTIC) {
-          nll_dlog_grad(xv[i], a[i], b[i], ga[i], gb[i]);
-          ga[i] *= c; gb[i] *= c;
+      for (int u = 0; u < U; ++u) {
+        const int j = j0 + u * G;
+        if (j < nvec) {
+          float ga[V], gb[V];
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            if constexpr (NLL == VAE_NLL_BERNOULLI) ga[i] = c * nll_bern_grad(xv[u][i], a[u][i]);
+            if constexpr (NLL == VAE_NLL_GAUSSIAN) {
+              nll_gauss_grad(xv[u][i], a[u][i], b[u][i], ga[i], gb[i]);
+              ga[i] *= c; gb[i] *= c;
+            }
+            if constexpr (NLL == VAE_NLL_DISC_LOGISTIC) {
+              nll_dlog_grad(xv[u][i], a[u][i], b[u][i], ga[i], gb[i]);
+              ga[i] *= c; gb[i] *= c;
+            }
+          }
+          store_vec<T, V>(gr + (int64_t)j * V, ga);
+          if constexpr (NLL != VAE_NLL_BERNOULLI) store_vec<T, V>(gr + D + (int64_t)j * V, gb);
         }
       }
-      store_vec<T, V>(gr + (int64_t)j * V, ga);
-      if constexpr (NLL != VAE_NLL_BERNOULLI) store_vec<T, V>(gr + D + (int64_t)j * V, gb);
     }
   }
 }
@@ -254,6 +267,7 @@ static RowGeom nll_geom(int64_t B, int64_t vecs_per_row) {
   RowGeom g = row_geom(B, vecs_per_row);
   if (vecs_per_row >= 1024 && g.tiles < 4 * 256) {
     g.G = kBlock;
+    g.U = 4;
     g.rows_per_block = 1;
     g.tiles = B;
     g.grid = (int)(g.tiles < kMaxGrid ? g.tiles : kMaxGrid);
@@ -270,13 +284,13 @@ static int nll_fwd_dispatch(const void* x, const void* recon, const void* kld, c
   const RowGeom g = nll_geom(B, vec ? D / VN : D);
   float* partials = loss ? workspace : nullptr;
   if (vec) {
-    hipLaunchKernelGGL((nll_elbo_fwd_kernel<T, VN, NLL>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)x,
-                       (const T*)recon, (const T*)kld, (const T*)add, (const T*)mi, (T*)nll, (T*)loss, (T*)elbo,
-                       partials, B, (int)D, kl_beta, g.G, g.tiles);
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_fwd_kernel<T, VN, NLL, U>), dim3(g.grid), dim3(kBlock), 0, stream,
+                                         (const T*)x, (const T*)recon, (const T*)kld, (const T*)add, (const T*)mi,
+                                         (T*)nll, (T*)loss, (T*)elbo, partials, B, (int)D, kl_beta, g.G, g.tiles));
   } else {
-    hipLaunchKernelGGL((nll_elbo_fwd_kernel<T, 1, NLL>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)x,
-                       (const T*)recon, (const T*)kld, (const T*)add, (const T*)mi, (T*)nll, (T*)loss, (T*)elbo,
-                       partials, B, (int)D, kl_beta, g.G, g.tiles);
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_fwd_kernel<T, 1, NLL, U>), dim3(g.grid), dim3(kBlock), 0, stream,
+                                         (const T*)x, (const T*)recon, (const T*)kld, (const T*)add, (const T*)mi,
+                                         (T*)nll, (T*)loss, (T*)elbo, partials, B, (int)D, kl_beta, g.G, g.tiles));
   }
   if (loss && means) launch_finalize(workspace, g.grid, 6, inv_count, means, stream);
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
@@ -290,13 +304,15 @@ static int nll_bwd_dispatch(const void* x, const void* recon, const void* gnll, 
   const bool vec = (D % VN == 0) && aligned16(x) && aligned16(recon) && aligned16(grecon);
   RowGeom g = nll_geom(B, vec ? D / VN : D);
   if (vec) {
-    hipLaunchKernelGGL((nll_elbo_bwd_kernel<T, VN, NLL>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)x,
-                       (const T*)recon, (const T*)gnll, (const T*)gloss, (const T*)gelbo, gmeans, (T*)grecon,
-                       (T*)gkld, (T*)gadd, (T*)gmi, B, (int)D, kl_beta, inv_count, g.G, g.tiles);
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_bwd_kernel<T, VN, NLL, U>), dim3(g.grid), dim3(kBlock), 0, stream,
+                                         (const T*)x, (const T*)recon, (const T*)gnll, (const T*)gloss,
+                                         (const T*)gelbo, gmeans, (T*)grecon, (T*)gkld, (T*)gadd, (T*)gmi, B, (int)D,
+                                         kl_beta, inv_count, g.G, g.tiles));
   } else {
-    hipLaunchKernelGGL((nll_elbo_bwd_kernel<T, 1, NLL>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)x,
-                       (const T*)recon, (const T*)gnll, (const T*)gloss, (const T*)gelbo, gmeans, (T*)grecon,
-                       (T*)gkld, (T*)gadd, (T*)gmi, B, (int)D, kl_beta, inv_count, g.G, g.tiles);
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_bwd_kernel<T, 1, NLL, U>), dim3(g.grid), dim3(kBlock), 0, stream,
+                                         (const T*)x, (const T*)recon, (const T*)gnll, (const T*)gloss,
+                                         (const T*)gelbo, gmeans, (T*)grecon, (T*)gkld, (T*)gadd, (T*)gmi, B, (int)D,
+                                         kl_beta, inv_count, g.G, g.tiles));
   }
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
@@ -346,10 +362,11 @@ extern "C" {
 int vae_nll_elbo_fwd(const void* x, const void* recon, int nll_type, const void* kld, const void* add, const void* mi,
                      float kl_beta, float inv_count, void* nll, void* loss, void* elbo, float* means,
                      float* workspace, int64_t B, int64_t D, int dtype, vae_stream_t stream) {
-  if (!x || !recon || !nll || B < 0 || D <= 0 || D > VAE_MAX_ROW) return VAE_ERR_ARG;
+  if (B < 0 || D <= 0 || D > VAE_MAX_ROW) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  if (!x || !recon || !nll) return VAE_ERR_ARG;
   if ((loss == nullptr) != (elbo == nullptr)) return VAE_ERR_ARG;
   if (loss && !workspace) return VAE_ERR_ARG;
-  if (B == 0) return VAE_OK;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32)
     return nll_fwd_type<float>(nll_type, x, recon, kld, add, mi, nll, loss, elbo, means, workspace, B, D, kl_beta,
@@ -363,8 +380,9 @@ int vae_nll_elbo_fwd(const void* x, const void* recon, int nll_type, const void*
 int vae_nll_elbo_bwd(const void* x, const void* recon, int nll_type, const void* gnll, const void* gloss,
                      const void* gelbo, const float* gmeans, float kl_beta, float inv_count, void* grecon, void* gkld,
                      void* gadd, void* gmi, int64_t B, int64_t D, int dtype, vae_stream_t stream) {
-  if (!x || !recon || !grecon || B < 0 || D <= 0 || D > VAE_MAX_ROW) return VAE_ERR_ARG;
+  if (B < 0 || D <= 0 || D > VAE_MAX_ROW) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
+  if (!x || !recon || !grecon) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32)
     return nll_bwd_type<float>(nll_type, x, recon, gnll, gloss, gelbo, gmeans, grecon, gkld, gadd, gmi, B, D,
@@ -378,8 +396,9 @@ int vae_nll_elbo_bwd(const void* x, const void* recon, int nll_type, const void*
 int vae_elbo_combine_fwd(const void* nll, const void* kld, const void* add, const void* mi, float kl_beta,
                          float inv_count, void* loss, void* elbo, float* means, float* workspace, int64_t B,
                          int dtype, vae_stream_t stream) {
-  if (!nll || !loss || !elbo || !workspace || B < 0) return VAE_ERR_ARG;
+  if (B < 0) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
+  if (!nll || !loss || !elbo || !workspace) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   int64_t blocks = (B + kBlock - 1) / kBlock;
   const int grid = (int)(blocks < kMaxGrid ? blocks : kMaxGrid);

@@ -19,7 +19,7 @@ namespace vae {
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-template <typename T, int V>
+template <typename T, int V, int U>
 __global__ __launch_bounds__(kBlock) void gauss_fwd_kernel(
     const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ noise, T* __restrict__ z,
     T* __restrict__ s_out, T* __restrict__ kl, float* __restrict__ partials, int64_t B, int L, float eps_tol,
@@ -35,33 +35,37 @@ __global__ __launch_bounds__(kBlock) void gauss_fwd_kernel(
     float klr = 0.f;
     if (row < B) {
       const T* lrow = logits + row * row_stride;
-#pragma unroll 2
-      for (int j = sub; j < nvec; j += G) {
-        float mu[V], s[V], e[V], zz[V];
-        load_vec<T, V>(lrow + (int64_t)j * V, mu);
-        load_vec<T, V>(lrow + L + (int64_t)j * V, s);
-        if (training) {
-          if (noise) {
-            load_vec<T, V>(noise + row * L + (int64_t)j * V, e);
-          } else {
-            philox_normal<V>(seed, offset, (uint64_t)(row0 + row) * (uint64_t)L + (uint64_t)j * V, e);
+      for (int j0 = sub; j0 < nvec; j0 += G * U) {
+        float mu[U][V], s[U][V], e[U][V];
+        load_chunk<T, V, U>(lrow, j0, G, nvec, mu);
+        load_chunk<T, V, U>(lrow + L, j0, G, nvec, s);
+        if (training && noise) load_chunk<T, V, U>(noise + row * L, j0, G, nvec, e);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = j0 + u * G;
+          if (j < nvec) {
+            if (training && !noise)
+              philox_normal<V>(seed, offset, (uint64_t)(row0 + row) * (uint64_t)L + (uint64_t)j * V, e[u]);
+            float zz[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+              // logvar = raw + eps_tol, rounded to the tensor dtype as the reference's add does
+              const float si = to_f32(from_f32<T>(add_rn(s[u][i], eps_tol)));
+              s[u][i] = si;
+              const float m = mu[u][i];
+              // z = fl(fl(e * fl(0.5*s)) + mu): separate roundings, no fma, as eps.mul(std).add_(mu)
+              zz[i] = training
+                          ? add_rn(to_f32(from_f32<T>(mul_rn(e[u][i], to_f32(from_f32<T>(mul_rn(0.5f, si)))))), m)
+                          : m;
+              const float s2 = si * si;
+              klr += 0.5f * (s2 + m * m - 1.0f - __logf(s2));
+              acc[0] += m;
+              acc[1] += si;
+            }
+            if (z) store_vec<T, V>(z + row * L + (int64_t)j * V, zz);
+            if (s_out) store_vec<T, V>(s_out + row * L + (int64_t)j * V, s[u]);
           }
         }
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-          // logvar = raw + eps_tol, rounded to the tensor dtype as the reference's add does
-          float si = to_f32(from_f32<T>(__fadd_rn(s[i], eps_tol)));
-          s[i] = si;
-          float m = mu[i];
-          // z = fl(fl(e * fl(0.5*s)) + mu): two roundings, no fma, as eps.mul(std).add_(mu)
-          zz[i] = training ? __fadd_rn(__fmul_rn(e[i], to_f32(from_f32<T>(0.5f * si))), m) : m;
-          float s2 = si * si;
-          klr += 0.5f * (s2 + m * m - 1.0f - logf(s2));
-          acc[0] += m;
-          acc[1] += si;
-        }
-        if (z) store_vec<T, V>(z + row * L + (int64_t)j * V, zz);
-        if (s_out) store_vec<T, V>(s_out + row * L + (int64_t)j * V, s);
       }
     }
     klr = group_sum(klr, G);
@@ -73,57 +77,51 @@ __global__ __launch_bounds__(kBlock) void gauss_fwd_kernel(
 // ---------------------------------------------------------------------------
 // backward: d logits from d z, d logvar, d kl and the two mean diagnostics
 // ---------------------------------------------------------------------------
-template <typename T, int V>
+template <typename T, int V, int U>
 __global__ __launch_bounds__(kBlock) void gauss_bwd_kernel(
     const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ noise, const T* __restrict__ gz,
     const T* __restrict__ gs, const T* __restrict__ gkl, const float* __restrict__ gmeans, T* __restrict__ glogits,
     int64_t B, int L, float eps_tol, float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0,
-    int G, int64_t tiles, int with_kl) {
+    int G, int64_t tiles) {
   const int rpb = kBlock / G;
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = L / V;
   const float gm_mu = gmeans ? gmeans[0] * mean_scale : 0.f;
   const float gm_s = gmeans ? gmeans[1] * mean_scale : 0.f;
+  const bool use_e = training && gz;  // d z / d s = 0.5 e only matters when z has a gradient
 
   for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
     const int64_t row = t * rpb + rloc;
     if (row >= B) continue;
     const T* lrow = logits + row * row_stride;
     T* grow = glogits + row * 2 * (int64_t)L;
-    const float gk = (gkl && with_kl) ? to_f32(gkl[row]) : 0.f;
-#pragma unroll 2
-    for (int j = sub; j < nvec; j += G) {
-      float mu[V], s[V], e[V], g[V], g2[V], dmu[V], ds[V];
-      load_vec<T, V>(lrow + (int64_t)j * V, mu);
-      load_vec<T, V>(lrow + L + (int64_t)j * V, s);
-      if (gz) {
-        load_vec<T, V>(gz + row * L + (int64_t)j * V, g);
-      } else {
+    const float gk = gkl ? to_f32(gkl[row]) : 0.f;
+    for (int j0 = sub; j0 < nvec; j0 += G * U) {
+      float mu[U][V], s[U][V], e[U][V], g[U][V], g2[U][V];
+      load_chunk<T, V, U>(lrow, j0, G, nvec, mu);
+      load_chunk<T, V, U>(lrow + L, j0, G, nvec, s);
+      if (gz) load_chunk<T, V, U>(gz + row * L, j0, G, nvec, g);
+      if (gs) load_chunk<T, V, U>(gs + row * L, j0, G, nvec, g2);
+      if (use_e && noise) load_chunk<T, V, U>(noise + row * L, j0, G, nvec, e);
 #pragma unroll
-        for (int i = 0; i < V; ++i) g[i] = 0.f;
-      }
-      if (gs) {
-        load_vec<T, V>(gs + row * L + (int64_t)j * V, g2);
-      } else {
+      for (int u = 0; u < U; ++u) {
+        const int j = j0 + u * G;
+        if (j < nvec) {
+          if (use_e && !noise)
+            philox_normal<V>(seed, offset, (uint64_t)(row0 + row) * (uint64_t)L + (uint64_t)j * V, e[u]);
+          float dmu[V], ds[V];
 #pragma unroll
-        for (int i = 0; i < V; ++i) g2[i] = 0.f;
-      }
-      if (training) {
-        if (noise) {
-          load_vec<T, V>(noise + row * L + (int64_t)j * V, e);
-        } else {
-          philox_normal<V>(seed, offset, (uint64_t)(row0 + row) * (uint64_t)L + (uint64_t)j * V, e);
+          for (int i = 0; i < V; ++i) {
+            const float si = to_f32(from_f32<T>(add_rn(s[u][i], eps_tol)));
+            const float gzi = gz ? g[u][i] : 0.f;
+            dmu[i] = gzi + gk * mu[u][i] + gm_mu;
+            ds[i] = (use_e ? 0.5f * e[u][i] * gzi : 0.f) + (gs ? g2[u][i] : 0.f) + gk * (si - fast_rcp(si)) + gm_s;
+          }
+          store_vec<T, V>(grow + (int64_t)j * V, dmu);
+          store_vec<T, V>(grow + L + (int64_t)j * V, ds);
         }
       }
-#pragma unroll
-      for (int i = 0; i < V; ++i) {
-        float si = to_f32(from_f32<T>(__fadd_rn(s[i], eps_tol)));
-        dmu[i] = g[i] + gk * mu[i] + gm_mu;
-        ds[i] = (training ? 0.5f * e[i] * g[i] : 0.f) + g2[i] + gk * (si - 1.0f / si) + gm_s;
-      }
-      store_vec<T, V>(grow + (int64_t)j * V, dmu);
-      store_vec<T, V>(grow + L + (int64_t)j * V, ds);
     }
   }
 }
@@ -227,23 +225,24 @@ __global__ __launch_bounds__(kBlock) void gauss_kl_bwd_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// finalize: out[k] = scale * sum_b partials[b*n + k]  (one block, fixed order)
+// finalize: out[k] = scale * sum_b partials[b*n + k], n <= 8.  One block, one pass:
+// thread t sums value k = t & 7 over blocks (t >> 3), (t >> 3) + 32, ... in double, then
+// thread k adds the 32 strided sums in a fixed order (deterministic, no atomics).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void finalize_kernel(const float* __restrict__ partials, int nblocks, int n,
                                                          float scale, float* __restrict__ out) {
-  __shared__ double lds[kBlock / 64];
-  for (int k = 0; k < n; ++k) {
-    double s = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += kBlock) s += (double)partials[(size_t)b * n + k];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double tot = 0.0;
-      for (int w = 0; w < kBlock / 64; ++w) tot += lds[w];
-      out[k] = (float)(tot * (double)scale);
-    }
-    __syncthreads();
+  __shared__ double lds[kBlock / 8][8];
+  const int k = threadIdx.x & 7, set = threadIdx.x >> 3;
+  double s = 0.0;
+  if (k < n)
+    for (int b = set; b < nblocks; b += kBlock / 8) s += (double)partials[(size_t)b * n + k];
+  lds[set][k] = s;
+  __syncthreads();
+  if (threadIdx.x < n) {
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 8; ++w) tot += lds[w][threadIdx.x];
+    out[threadIdx.x] = (float)(tot * (double)scale);
   }
 }
 
@@ -261,13 +260,13 @@ static int gauss_fwd_dispatch(const void* logits, int64_t row_stride, const void
                    (!noise || aligned16(noise)) && (!s_out || aligned16(s_out));
   const RowGeom g = row_geom(B, vec ? L / VN : L);
   if (vec) {
-    hipLaunchKernelGGL((gauss_fwd_kernel<T, VN>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)logits, row_stride,
-                       (const T*)noise, (T*)z, (T*)s_out, (T*)kl, workspace, B, (int)L, eps_tol, training, seed,
-                       offset, row0, g.G, g.tiles);
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gauss_fwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
+                                         (const T*)logits, row_stride, (const T*)noise, (T*)z, (T*)s_out, (T*)kl,
+                                         workspace, B, (int)L, eps_tol, training, seed, offset, row0, g.G, g.tiles));
   } else {
-    hipLaunchKernelGGL((gauss_fwd_kernel<T, 1>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)logits, row_stride,
-                       (const T*)noise, (T*)z, (T*)s_out, (T*)kl, workspace, B, (int)L, eps_tol, training, seed,
-                       offset, row0, g.G, g.tiles);
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gauss_fwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, stream,
+                                         (const T*)logits, row_stride, (const T*)noise, (T*)z, (T*)s_out, (T*)kl,
+                                         workspace, B, (int)L, eps_tol, training, seed, offset, row0, g.G, g.tiles));
   }
   if (means) launch_finalize(workspace, g.grid, 2, mean_scale, means, stream);
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
@@ -283,13 +282,15 @@ static int gauss_bwd_dispatch(const void* logits, int64_t row_stride, const void
                    (!noise || aligned16(noise)) && (!gz || aligned16(gz)) && (!gs || aligned16(gs));
   const RowGeom g = row_geom(B, vec ? L / VN : L);
   if (vec) {
-    hipLaunchKernelGGL((gauss_bwd_kernel<T, VN>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)logits, row_stride,
-                       (const T*)noise, (const T*)gz, (const T*)gs, (const T*)gkl, gmeans, (T*)glogits, B, (int)L,
-                       eps_tol, mean_scale, training, seed, offset, row0, g.G, g.tiles, 1);
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gauss_bwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
+                                         (const T*)logits, row_stride, (const T*)noise, (const T*)gz, (const T*)gs,
+                                         (const T*)gkl, gmeans, (T*)glogits, B, (int)L, eps_tol, mean_scale, training,
+                                         seed, offset, row0, g.G, g.tiles));
   } else {
-    hipLaunchKernelGGL((gauss_bwd_kernel<T, 1>), dim3(g.grid), dim3(kBlock), 0, stream, (const T*)logits, row_stride,
-                       (const T*)noise, (const T*)gz, (const T*)gs, (const T*)gkl, gmeans, (T*)glogits, B, (int)L,
-                       eps_tol, mean_scale, training, seed, offset, row0, g.G, g.tiles, 1);
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gauss_bwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, stream,
+                                         (const T*)logits, row_stride, (const T*)noise, (const T*)gz, (const T*)gs,
+                                         (const T*)gkl, gmeans, (T*)glogits, B, (int)L, eps_tol, mean_scale, training,
+                                         seed, offset, row0, g.G, g.tiles));
   }
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
@@ -346,9 +347,9 @@ int vae_gauss_reparam_kl_fwd(const void* logits, int64_t row_stride, const void*
                              void* kl, float* means, float* workspace, int64_t B, int64_t L, float eps_tol,
                              float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0, int dtype,
                              vae_stream_t stream) {
-  if (!logits || (!z && training) || !kl || !workspace || B < 0 || L <= 0 || L > VAE_MAX_ROW || row_stride < 2 * L)
-    return VAE_ERR_ARG;
+  if (B < 0 || L <= 0 || L > VAE_MAX_ROW) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
+  if (!logits || (!z && training) || !kl || !workspace || row_stride < 2 * L) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32)
     return gauss_fwd_dispatch<float>(logits, row_stride, noise, z, s_out, kl, means, workspace, B, L, eps_tol,
@@ -363,8 +364,9 @@ int vae_gauss_reparam_kl_bwd(const void* logits, int64_t row_stride, const void*
                              const void* gs, const void* gkl, const float* gmeans, void* glogits, int64_t B,
                              int64_t L, float eps_tol, float mean_scale, int training, uint64_t seed,
                              uint64_t offset, int64_t row0, int dtype, vae_stream_t stream) {
-  if (!logits || !glogits || B < 0 || L <= 0 || L > VAE_MAX_ROW || row_stride < 2 * L) return VAE_ERR_ARG;
+  if (B < 0 || L <= 0 || L > VAE_MAX_ROW) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
+  if (!logits || !glogits || row_stride < 2 * L) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32)
     return gauss_bwd_dispatch<float>(logits, row_stride, noise, gz, gs, gkl, gmeans, glogits, B, L, eps_tol,
@@ -378,9 +380,9 @@ int vae_gauss_reparam_kl_bwd(const void* logits, int64_t row_stride, const void*
 int vae_gauss_kl_fwd(const void* mu_q, int64_t stride_mu_q, const void* s_q, int64_t stride_s_q, const void* mu_p,
                      int64_t stride_mu_p, const void* s_p, int64_t stride_s_p, void* kl, int64_t B, int64_t L,
                      int dtype, vae_stream_t stream) {
-  if (!mu_q || !s_q || !kl || B < 0 || L <= 0 || L > VAE_MAX_ROW || ((mu_p == nullptr) != (s_p == nullptr)))
-    return VAE_ERR_ARG;
+  if (B < 0 || L <= 0 || L > VAE_MAX_ROW) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
+  if (!mu_q || !s_q || !kl || ((mu_p == nullptr) != (s_p == nullptr))) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32)
     return gauss_kl_fwd_dispatch<float>(mu_q, stride_mu_q, s_q, stride_s_q, mu_p, stride_mu_p, s_p, stride_s_p, kl,
@@ -394,10 +396,11 @@ int vae_gauss_kl_fwd(const void* mu_q, int64_t stride_mu_q, const void* s_q, int
 int vae_gauss_kl_bwd(const void* mu_q, int64_t stride_mu_q, const void* s_q, int64_t stride_s_q, const void* mu_p,
                      int64_t stride_mu_p, const void* s_p, int64_t stride_s_p, const void* gkl, void* g_mu_q,
                      void* g_s_q, void* g_mu_p, void* g_s_p, int64_t B, int64_t L, int dtype, vae_stream_t stream) {
-  if (!mu_q || !s_q || !gkl || !g_mu_q || !g_s_q || B < 0 || L <= 0 || L > VAE_MAX_ROW ||
-      ((mu_p == nullptr) != (s_p == nullptr)) || ((g_mu_p == nullptr) != (g_s_p == nullptr)) || (g_mu_p && !mu_p))
-    return VAE_ERR_ARG;
+  if (B < 0 || L <= 0 || L > VAE_MAX_ROW) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
+  if (!mu_q || !s_q || !gkl || !g_mu_q || !g_s_q || ((mu_p == nullptr) != (s_p == nullptr)) ||
+      ((g_mu_p == nullptr) != (g_s_p == nullptr)) || (g_mu_p && !mu_p))
+    return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32)
     return gauss_kl_bwd_dispatch<float>(mu_q, stride_mu_q, s_q, stride_s_q, mu_p, stride_mu_p, s_p, stride_s_p, gkl,

@@ -93,7 +93,7 @@ def gauss_reparam_kl(logits, noise=None, eps_tol=1e-6, training=True, seed=0, of
     """
     logits = _rows(logits)
     if noise is not None:
-        noise = noise.reshape(logits.shape[0], -1).contiguous()
+        noise = noise.reshape(logits.shape[0], logits.shape[1] // 2).contiguous()
     z, logvar, kl, means = _GaussReparamKL.apply(logits, noise, float(eps_tol), bool(training), int(seed),
                                                  int(offset), int(row0), mean_scale)
     return (z if training else None), logvar, kl, means

@@ -1,0 +1,111 @@
+"""IsotropicGaussian with the reference's interface (reparameterizers/isotropic_gaussian.py),
+routed through the fused HIP kernels.
+
+forward(): one launch does the mu/logvar split, `+ eps`, `z = e*(0.5*logvar) + mu` (NO exp,
+reference :87-92), KL vs N(0,1) (:158-170) and the two means (:213-214).  The KL is kept on
+the returned `logvar` tensor so that kl(params) costs nothing; kl() on foreign params or with a
+prior runs the standalone KL kernel.  No CPU path: CPU tensors raise.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.distributions as D
+
+from .. import functional as F_
+from .. import rng
+
+EPS_TOL = 1e-6  # helpers.utils.eps(half=False): assumed, helpers is un-vendored
+
+
+class IsotropicGaussian(nn.Module):
+    def __init__(self, config):
+        super(IsotropicGaussian, self).__init__()
+        self.is_discrete = False
+        self.config = config
+        self.input_size = self.config['continuous_size']
+        assert self.config['continuous_size'] % 2 == 0
+        self.output_size = self.config['continuous_size'] // 2
+        self.row_offset = 0       # first global row of this rank's shard (set by vae_amd.dist)
+        self.mean_scale = None    # 1/(B_global*L) when sharded
+
+    # ---- prior helpers: plain PyTorch, as in the reference (:28-75) --------------------
+    def _new(self, *shape):
+        dev = 'cuda' if self.config.get('cuda', True) else 'cpu'
+        return torch.zeros(*shape, dtype=torch.float16 if self.config.get('half') else torch.float32, device=dev)
+
+    def prior_params(self, batch_size, **kwargs):
+        mu = self._new(batch_size, self.output_size)
+        scale_var = 1.0 if 'scale_var' not in kwargs else kwargs['scale_var']
+        sigma = self._new(batch_size, self.output_size) + scale_var
+        return {'gaussian': {'mu': mu, 'logvar': sigma}}
+
+    def prior_distribution(self, batch_size, **kwargs):
+        params = self.prior_params(batch_size, **kwargs)
+        return D.Normal(params['gaussian']['mu'], params['gaussian']['logvar'], validate_args=False)
+
+    def prior(self, batch_size, **kwargs):
+        scale_var = 1.0 if 'scale_var' not in kwargs else kwargs['scale_var']
+        return self._new(batch_size, self.output_size).normal_(mean=0, std=scale_var)
+
+    def get_reparameterizer_scalars(self):
+        return {}
+
+    # ---- the hot path ------------------------------------------------------------------
+    def reparmeterize(self, logits, force=False, noise=None):
+        dim_map = {2: -1, 3: -1, 4: 1}
+        assert logits.dim() in dim_map, "unknown number of dims for isotropic gauss reparam"
+        dim2slice = dim_map[logits.dim()]
+        feature_size = logits.shape[dim2slice]
+        assert feature_size % 2 == 0, "feature dimension not divisible by 2 for mu/sigma^2."
+        assert feature_size // 2 == self.output_size, \
+            "feature_size = {} but requested output_size = {}".format(feature_size, self.output_size)
+        L = feature_size // 2
+        training = bool(self.training or force)
+        mu = torch.narrow(logits, dim2slice, 0, L)  # a view of logits, as in the reference
+
+        if logits.dim() == 4:
+            # [B, C, H, W] sliced on channels, KL summed over W only: repack rows as [mu(W) | s(W)]
+            W = logits.shape[-1]
+            s_raw = torch.narrow(logits, dim2slice, L, L)
+            rows = torch.cat([mu.reshape(-1, W), s_raw.reshape(-1, W)], -1)
+            out_shape, kl_shape = mu.shape, mu.shape[:-1]
+        else:
+            rows = logits
+            out_shape, kl_shape = mu.shape, mu.shape[:-1]
+
+        seed, offset = (0, 0)
+        if training and noise is None:
+            seed, offset = rng.next_call()
+        z, logvar, kl, means = F_.gauss_reparam_kl(rows, noise=noise, eps_tol=EPS_TOL, training=training, seed=seed,
+                                                   offset=offset, row0=self.row_offset, mean_scale=self.mean_scale)
+        logvar = logvar.reshape(out_shape)
+        z = z.reshape(out_shape) if training else mu
+        logvar._vae_amd_kl = (kl.reshape(kl_shape), mu)   # consumed by kl(); invisible to dict consumers
+        logvar._vae_amd_means = means
+        return z, {'z': z, 'mu': mu, 'logvar': logvar}
+
+    def forward(self, logits, force=False, noise=None):
+        z, gauss_params = self.reparmeterize(logits, force=force, noise=noise)
+        means = gauss_params['logvar']._vae_amd_means.to(logits.dtype)
+        gauss_params['mu_mean'] = means[0]
+        gauss_params['logvar_mean'] = means[1]
+        return z, {'z': z, 'logits': logits, 'gaussian': gauss_params}
+
+    def kl(self, dist_a, prior=None):
+        g = dist_a['gaussian']
+        if prior is None:
+            fused = getattr(g['logvar'], '_vae_amd_kl', None)
+            if fused is not None and fused[1] is g['mu']:
+                return fused[0]
+            return F_.gauss_kl(g['mu'], g['logvar'])
+        return F_.gauss_kl(g['mu'], g['logvar'], prior['gaussian']['mu'], prior['gaussian']['logvar'])
+
+    def mutual_info(self, params, eps=None):
+        kl_proxy_to_xent = F_.gauss_kl(params['gaussian']['mu'], params['gaussian']['logvar'],
+                                       params['q_z_given_xhat']['gaussian']['mu'],
+                                       params['q_z_given_xhat']['gaussian']['logvar'])
+        return self.config['continuous_mut_info'] * kl_proxy_to_xent
+
+    def log_likelihood(self, z, params):
+        return -(0.5 * np.log(2 * np.pi) + params['gaussian']['logvar']) \
+            - 0.5 * ((z - params['gaussian']['mu']) / torch.exp(params['gaussian']['logvar'])) ** 2

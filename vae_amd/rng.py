@@ -1,0 +1,22 @@
+"""Counter-based noise bookkeeping for the in-kernel Philox draws.
+
+The reference draws from torch's global generator (isotropic_gaussian.py:88, gumbel.py:269,
+torch/distributions/relaxed_bernoulli.py:105).  The kernels instead key Philox4x32-10 by
+(seed, call offset, global row, column): `seed` is torch's global seed, `offset` a per-process
+call counter that restarts whenever the seed changes, so `torch.manual_seed(s)` still makes a
+run reproducible, and a sample's noise does not depend on how the batch is sharded over ranks.
+For parity tests noise is injected explicitly and none of this is used.
+"""
+import torch
+
+_state = {'seed': None, 'offset': 0}
+
+
+def next_call():
+    """(seed, offset) for one kernel call that draws noise."""
+    seed = torch.initial_seed()
+    if seed != _state['seed']:
+        _state['seed'] = seed
+        _state['offset'] = 0
+    _state['offset'] += 1
+    return seed, _state['offset']
