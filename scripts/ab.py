@@ -1,0 +1,82 @@
+"""Tuning aid (GPU box): interleaved A/B of library builds x runtime knobs in ONE process.
+
+    python scripts/ab.py 'lib=a.so,b.so' 'G=auto,32' 'U=auto,4' 'MAXGRID=2048,1000000' [kernels=...]
+Each variant is timed in rounds (5 launches per round, 12 rounds, interleaved); median per variant."""
+import ctypes
+import itertools
+import os
+import statistics
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vae_amd import _lib
+
+opts = dict(a.split('=', 1) for a in sys.argv[1:])
+libs = opts.get('lib', 'vae_amd/libvae_amd.so').split(',')
+knobs = {k: opts.get(k, 'auto').split(',') for k in ('G', 'U', 'MAXGRID')}
+only = opts.get('kernels', '').split(',') if opts.get('kernels') else None
+B, L, D = int(opts.get('B', 65536)), int(opts.get('L', 512)), int(opts.get('D', 784))
+dev = torch.device('cuda', 0)
+f32 = dict(dtype=torch.float32, device=dev)
+logits = torch.randn(B, 2 * L, **f32); noise = torch.randn(B, L, **f32)
+x = (torch.rand(B, D, **f32) < 0.13).float(); recon = torch.randn(B, D, **f32)
+gz = torch.randn(B, L, **f32)
+z = torch.empty(B, L, **f32); logvar = torch.empty(B, L, **f32); kl = torch.empty(B, **f32)
+nll = torch.empty(B, **f32); loss = torch.empty(B, **f32); elbo = torch.empty(B, **f32)
+scal = torch.zeros(8, **f32); gmeans = torch.zeros(6, **f32); gmeans[0] = 1
+grecon = torch.empty(B, D, **f32); gkld = torch.empty(B, **f32); glogits = torch.empty(B, 2 * L, **f32)
+ws = torch.empty(1 << 16, **f32)
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+p = lambda t: ctypes.c_void_p(t.data_ptr())
+
+handles = {}
+for path in libs:
+    lib = ctypes.CDLL(os.path.abspath(path))
+    for name, argt in _lib.SIGNATURES.items():
+        if hasattr(lib, name):
+            getattr(lib, name).argtypes = argt
+    handles[path] = lib
+
+
+def kernels(lib):
+    return {
+        'gauss_fwd': (lambda: lib.vae_gauss_reparam_kl_fwd(p(logits), 2 * L, p(noise), p(z), p(logvar), p(kl), p(scal), p(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st), (16 * L + 4) * B),
+        'gauss_bwd': (lambda: lib.vae_gauss_reparam_kl_bwd(p(logits), 2 * L, p(noise), p(gz), None, p(gkld), None, p(glogits), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st), (24 * L + 4) * B),
+        'nll_fwd': (lambda: lib.vae_nll_elbo_fwd(p(x), p(recon), 0, p(kl), None, None, 1.0, 1.0 / B, p(nll), p(loss), p(elbo), p(scal), p(ws), B, D, 0, st), (8 * D + 12) * B),
+        'nll_bwd': (lambda: lib.vae_nll_elbo_bwd(p(x), p(recon), 0, None, None, None, p(gmeans), 1.0, 1.0 / B, p(grecon), p(gkld), None, None, B, D, 0, st), 12 * D * B),
+    }
+
+
+variants = list(itertools.product(libs, knobs['G'], knobs['U'], knobs['MAXGRID']))
+
+
+def setenv(G, U, MG):
+    for k, v in (('VAE_AMD_G', G), ('VAE_AMD_U', U), ('VAE_AMD_MAXGRID', MG)):
+        if v == 'auto':
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+names = [n for n in kernels(handles[libs[0]]) if not only or n in only]
+for kname in names:
+    times = {v: [] for v in variants}
+    for rnd in range(12):
+        for v in variants:
+            setenv(*v[1:])
+            fn, nbytes = kernels(handles[v[0]])[kname]
+            if rnd == 0:
+                for _ in range(3):
+                    assert fn() == 0
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            times[v].append(e0.elapsed_time(e1) / 5)
+    for v in variants:
+        med, mn = statistics.median(times[v]), min(times[v])
+        print('%-10s %-28s G=%-4s U=%-4s grid=%-8s med %.4f ms %5.0f GB/s (%.1f%%)  min %.4f ms %5.0f GB/s' % (
+            kname, os.path.basename(v[0]), v[1], v[2], v[3], med, nbytes / med / 1e6, nbytes / med / 1e6 / 80,
+            mn, nbytes / mn / 1e6), flush=True)

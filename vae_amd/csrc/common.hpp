@@ -59,7 +59,9 @@ __device__ __forceinline__ float div_rn(float a, float b) {
 
 // 16-byte packets: the widest per-lane access (global_load/store_dwordx4).  Every tensor on
 // this path is streamed exactly once per kernel, so loads and stores carry the non-temporal
-// hint (no reuse to keep in L2 / Infinity Cache).
+// hint (no reuse to keep in L2 / Infinity Cache).  Measured on MI355X (scripts/ab.py, interleaved
+// in one process, B=65536): nt loads +8..15 % on the gauss kernels, nt stores -5..-15 %, so
+// loads are non-temporal and stores are plain.
 template <typename T, int V>
 struct PackOf;
 template <>
@@ -80,7 +82,7 @@ struct VecOf {
 #define VAE_NT_LOAD 1
 #endif
 #ifndef VAE_NT_STORE
-#define VAE_NT_STORE 1
+#define VAE_NT_STORE 0
 #endif
 
 template <typename T, int V>
@@ -272,23 +274,20 @@ struct RowGeom {
   int grid;            // min(tiles, kMaxGrid)
 };
 
-// Pick lanes-per-row: the G (8..64) that wastes the fewest lane slots over whole U=4 passes,
-// larger G on ties (longer contiguous runs per load instruction).  Short rows get the smallest
-// power of two that covers them.  VAE_AMD_G overrides (tuning only).
-inline RowGeom row_geom(int64_t rows, int64_t vecs_per_row) {
+// Lanes per row: a whole wave (G = 64: 1 KiB contiguous per load/store instruction) once the
+// row has at least 64 vectors, else the smallest power of two that covers it.  Measured
+// (scripts/ab.py): for 784-pixel rows G = 64 beats G = 8/16 by 20-45 % on the store-heavy
+// backward although 23 % of the lane slots of the last pass idle.
+// Grid: kernels with a per-block epilogue (block partials of the batch means) run best with
+// 4 resident blocks per CU (cap 1024); pure streaming kernels get one tile per block.
+// VAE_AMD_G / VAE_AMD_U / VAE_AMD_MAXGRID override (tuning only).
+constexpr int kGridReduce = 1024;
+constexpr int64_t kGridStream = 1 << 20;
+
+inline RowGeom row_geom(int64_t rows, int64_t vecs_per_row, int64_t max_grid = kGridReduce) {
   RowGeom g;
   int G = 1;
-  if (vecs_per_row <= 64) {
-    while (G < vecs_per_row) G <<= 1;
-  } else {
-    double best = -1.0;
-    for (int c = 64; c >= 8; c >>= 1) {
-      const int64_t span = (int64_t)c * 4;
-      const int64_t slots = (vecs_per_row + span - 1) / span * span;
-      const double eff = (double)vecs_per_row / (double)slots;
-      if (eff > best + 0.02) { best = eff; G = c; }
-    }
-  }
+  while (G < 64 && G < vecs_per_row) G <<= 1;
   if (const char* e = getenv("VAE_AMD_G")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) G = v;
@@ -296,9 +295,17 @@ inline RowGeom row_geom(int64_t rows, int64_t vecs_per_row) {
   g.G = G;
   const int64_t iters = (vecs_per_row + G - 1) / G;
   g.U = iters >= 3 ? 4 : (iters == 2 ? 2 : 1);
+  if (const char* e = getenv("VAE_AMD_U")) {
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4) g.U = v;
+  }
+  if (const char* e = getenv("VAE_AMD_MAXGRID")) {
+    const int64_t v = atoll(e);
+    if (v >= 1) max_grid = (max_grid <= kMaxGrid && v > kMaxGrid) ? kMaxGrid : v;  // partials buffer bound
+  }
   g.rows_per_block = kBlock / G;
   g.tiles = (rows + g.rows_per_block - 1) / g.rows_per_block;
-  g.grid = (int)(g.tiles < kMaxGrid ? g.tiles : kMaxGrid);
+  g.grid = (int)(g.tiles < max_grid ? g.tiles : max_grid);
   if (g.grid < 1) g.grid = 1;
   return g;
 }

@@ -263,14 +263,14 @@ __global__ __launch_bounds__(kBlock) void elbo_combine_bwd_kernel(
 void launch_finalize(const float* partials, int nblocks, int n, float scale, float* out, hipStream_t stream);
 
 // Long rows with few samples: give a row to the whole block so the chip stays full.
-static RowGeom nll_geom(int64_t B, int64_t vecs_per_row) {
-  RowGeom g = row_geom(B, vecs_per_row);
+static RowGeom nll_geom(int64_t B, int64_t vecs_per_row, int64_t max_grid) {
+  RowGeom g = row_geom(B, vecs_per_row, max_grid);
   if (vecs_per_row >= 1024 && g.tiles < 4 * 256) {
     g.G = kBlock;
     g.U = 4;
     g.rows_per_block = 1;
     g.tiles = B;
-    g.grid = (int)(g.tiles < kMaxGrid ? g.tiles : kMaxGrid);
+    g.grid = (int)(g.tiles < max_grid ? g.tiles : max_grid);
   }
   return g;
 }
@@ -281,7 +281,7 @@ static int nll_fwd_dispatch(const void* x, const void* recon, const void* kld, c
                             float kl_beta, float inv_count, hipStream_t stream) {
   constexpr int VN = VecOf<T>::n;
   const bool vec = (D % VN == 0) && aligned16(x) && aligned16(recon);
-  const RowGeom g = nll_geom(B, vec ? D / VN : D);
+  const RowGeom g = nll_geom(B, vec ? D / VN : D, kGridReduce);
   float* partials = loss ? workspace : nullptr;
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_fwd_kernel<T, VN, NLL, U>), dim3(g.grid), dim3(kBlock), 0, stream,
@@ -302,7 +302,7 @@ static int nll_bwd_dispatch(const void* x, const void* recon, const void* gnll, 
                             int64_t D, float kl_beta, float inv_count, hipStream_t stream) {
   constexpr int VN = VecOf<T>::n;
   const bool vec = (D % VN == 0) && aligned16(x) && aligned16(recon) && aligned16(grecon);
-  RowGeom g = nll_geom(B, vec ? D / VN : D);
+  RowGeom g = nll_geom(B, vec ? D / VN : D, kGridStream);
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_bwd_kernel<T, VN, NLL, U>), dim3(g.grid), dim3(kBlock), 0, stream,
                                          (const T*)x, (const T*)recon, (const T*)gnll, (const T*)gloss,

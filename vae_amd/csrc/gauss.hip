@@ -280,7 +280,7 @@ static int gauss_bwd_dispatch(const void* logits, int64_t row_stride, const void
   constexpr int VN = VecOf<T>::n;
   const bool vec = (L % VN == 0) && (row_stride % VN == 0) && aligned16(logits) && aligned16(glogits) &&
                    (!noise || aligned16(noise)) && (!gz || aligned16(gz)) && (!gs || aligned16(gs));
-  const RowGeom g = row_geom(B, vec ? L / VN : L);
+  const RowGeom g = row_geom(B, vec ? L / VN : L, kGridStream);
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gauss_bwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
                                          (const T*)logits, row_stride, (const T*)noise, (const T*)gz, (const T*)gs,
