@@ -39,6 +39,9 @@ enum { VAE_F32 = 0, VAE_BF16 = 1 };
 enum { VAE_NLL_BERNOULLI = 0, VAE_NLL_GAUSSIAN = 1, VAE_NLL_DISC_LOGISTIC = 2 };
 
 #define VAE_MAX_ROW (1 << 24) /* longest supported row (elements) */
+/* softmax-class kernels keep the row in registers: 4 x 256 16-byte vectors (fp32; bf16 rows
+ * may be twice as long when K % 8 == 0); unaligned rows (K % 4 != 0) are limited to 1024.   */
+#define VAE_MAX_SOFTMAX_ROW 4096
 
 /* ABI version of this header; bumped on any signature change. */
 int vae_abi_version(void);
@@ -79,6 +82,81 @@ int vae_gauss_kl_fwd(const void* mu_q, int64_t stride_mu_q, const void* s_q, int
 int vae_gauss_kl_bwd(const void* mu_q, int64_t stride_mu_q, const void* s_q, int64_t stride_s_q, const void* mu_p,
                      int64_t stride_mu_p, const void* s_p, int64_t stride_s_p, const void* gkl, void* g_mu_q,
                      void* g_s_q, void* g_mu_p, void* g_s_p, int64_t B, int64_t L, int dtype, vae_stream_t stream);
+
+/* ---- GumbelSoftmax ----------------------------------------------------------
+ * reparameterizers/gumbel.py:110-124 (log_q_z = log_softmax(logits)), :257-278
+ * (g = -log(-log(U + 1e-9) + 1e-9); y = softmax((logits + g)/tau + 1e-9); the
+ * reference draws U on the CPU and copies it to the device every step), :281-304
+ * (h = (y == rowmax(y)), multi-hot on ties; z_hard = (h - y).detach() + y).
+ *   logits [B, K] rows `row_stride` apart; unif [B, K] uniform draws or NULL
+ *   (Philox keyed by (seed, offset, row0 + row, col)); y, z_hard, log_q_z [B, K].
+ *   K <= VAE_MAX_SOFTMAX_ROW.                                                     */
+int vae_gumbel_fwd(const void* logits, int64_t row_stride, const void* unif, void* y, void* z_hard, void* log_q_z,
+                   int64_t B, int64_t K, float tau, uint64_t seed, uint64_t offset, int64_t row0, int dtype,
+                   vae_stream_t stream);
+/* glogits [B, K] from the grads of y, z_hard (straight-through: passes to y) and
+ * log_q_z (each may be NULL), using the saved outputs y and log_q_z.              */
+int vae_gumbel_bwd(const void* y, const void* log_q_z, const void* gy, const void* gz_hard, const void* glog_q_z,
+                   void* glogits, int64_t B, int64_t K, float tau, int dtype, vae_stream_t stream);
+/* Categorical KL, reparameterizers/gumbel.py:222-254 (_kl_tf_version over two
+ * OneHotCategorical(logits=log_q_z)): kl[b] = sum softmax(q)*(log_softmax(q) -
+ * log_softmax(p)).  log_q / log_p: strided [B, K] views; g_log_p may be NULL.     */
+int vae_categorical_kl_fwd(const void* log_q, int64_t stride_q, const void* log_p, int64_t stride_p, void* kl,
+                           int64_t B, int64_t K, int dtype, vae_stream_t stream);
+int vae_categorical_kl_bwd(const void* log_q, int64_t stride_q, const void* log_p, int64_t stride_p, const void* gkl,
+                           void* g_log_q, void* g_log_p, int64_t B, int64_t K, int dtype, vae_stream_t stream);
+
+/* ---- Bernoulli (relaxed) ----------------------------------------------------
+ * reparameterizers/bernoulli.py:126-136 via torch/distributions/relaxed_bernoulli.py:104-112
+ * (p = clamp(sigmoid(l)), u = clamp(U), y = sigmoid((log u - log1p(-u) + log p - log1p(-p))/tau)),
+ * bernoulli.py:111-124 (hard = y >= 0.5; z_hard = (hard - y).detach() + y).
+ *   logits [B, K] rows `row_stride` apart; unif [B, K] or NULL (Philox); y, z_hard [B, K].  */
+int vae_bernoulli_fwd(const void* logits, int64_t row_stride, const void* unif, void* y, void* z_hard, int64_t B,
+                      int64_t K, float tau, uint64_t seed, uint64_t offset, int64_t row0, int dtype,
+                      vae_stream_t stream);
+int vae_bernoulli_bwd(const void* logits, int64_t row_stride, const void* y, const void* gy, const void* gz_hard,
+                      void* glogits, int64_t B, int64_t K, float tau, int dtype, vae_stream_t stream);
+/* bernoulli.py:147-191: sum over the last dim of q1*(log(q1+1e-6) - log(p1+1e-6)) +
+ * q0*(log(q0+1e-6) - log(p0+1e-6)); logits_p NULL = the uniform prior p = 0.5.     */
+int vae_bernoulli_kl_fwd(const void* logits_q, int64_t stride_q, const void* logits_p, int64_t stride_p, void* kl,
+                         int64_t B, int64_t K, int dtype, vae_stream_t stream);
+int vae_bernoulli_kl_bwd(const void* logits_q, int64_t stride_q, const void* logits_p, int64_t stride_p,
+                         const void* gkl, void* g_logits_q, void* g_logits_p, int64_t B, int64_t K, int dtype,
+                         vae_stream_t stream);
+
+/* ---- Beta ---------------------------------------------------------------------
+ * reparameterizers/beta.py:105-106 (conc1/conc2 = sigmoid of the two halves),
+ * :110-124 (KL vs Beta(1.1, 1.1), torch/distributions/kl.py:219-228), :175-176 (means).
+ * The sample stays torch (Beta.rsample is an ATen rejection sampler, not injectable).
+ *   logits [B, 2L]; conc1, conc2 [B, L]; kl [B]; means: 2 floats * mean_scale or NULL.   */
+int vae_beta_split_kl_fwd(const void* logits, int64_t row_stride, void* conc1, void* conc2, void* kl, float* means,
+                          float* workspace, int64_t B, int64_t L, float mean_scale, int dtype, vae_stream_t stream);
+int vae_beta_split_kl_bwd(const void* logits, int64_t row_stride, const void* gconc1, const void* gconc2,
+                          const void* gkl, const float* gmeans, void* glogits, int64_t B, int64_t L, float mean_scale,
+                          int dtype, vae_stream_t stream);
+/* beta.py:126-136: KL(Beta(a1, a0) || Beta(b1, b0)) summed over the last dim; b1 = b0 = NULL
+ * means Beta(1.1, 1.1).  Strided [B, L] views; gb1/gb0 may be NULL.                  */
+int vae_beta_kl_fwd(const void* a1, int64_t stride_a1, const void* a0, int64_t stride_a0, const void* b1,
+                    int64_t stride_b1, const void* b0, int64_t stride_b0, void* kl, int64_t B, int64_t L, int dtype,
+                    vae_stream_t stream);
+int vae_beta_kl_bwd(const void* a1, int64_t stride_a1, const void* a0, int64_t stride_a0, const void* b1,
+                    int64_t stride_b1, const void* b0, int64_t stride_b0, const void* gkl, void* ga1, void* ga0,
+                    void* gb1, void* gb0, int64_t B, int64_t L, int dtype, vae_stream_t stream);
+
+/* ---- Flow "KL" ----------------------------------------------------------------
+ * reparameterizers/flow.py:67-78.  cross_batch = 1 (2-D logits, logdet [B,1], R = 1):
+ * kl_i = mean_j(sum_f 0.5 u_jf^2 + F/2 log 2pi) - logdet_i -- the reference's [B,B]
+ * broadcast in O(B*F).  phase 0 = both steps; phase 1 = row values into kl and
+ * their sum * inv_count into mean_io[0] (all-reduce it when the batch is sharded);
+ * phase 2 = kl_i = mean_io[0] - logdet_i.  cross_batch = 0 (3-D logits [B,R,F], logdet
+ * [B,R]): kl_i = mean_r(nlp_ir - logdet_ir).                                        */
+int vae_flow_kl_fwd(const void* u, const void* logdet, int64_t R, void* kl, float* mean_io, float* workspace,
+                    int64_t B, int64_t F, float inv_count, int cross_batch, int phase, int dtype,
+                    vae_stream_t stream);
+/* gu[row, :] = c * u[row, :], c = gsum[0] * scale (cross-batch: gsum = sum_i gkl_i, scale =
+ * inv_count) or gkl[row] * scale (per-sample rows of row_len = R*F, scale = 1/R).      */
+int vae_flow_kl_bwd(const void* u, const void* gkl, const float* gsum, void* gu, int64_t B, int64_t row_len,
+                    float scale, int dtype, vae_stream_t stream);
 
 /* ---- NLL + ELBO -------------------------------------------------------------
  * abstract_vae.py:461-471 (nll -> helpers.distributions.nll, un-vendored: the

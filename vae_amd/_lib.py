@@ -30,6 +30,20 @@ SIGNATURES = {
     'vae_gauss_reparam_kl_bwd': [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _f, _f, _i, _u64, _u64, _i64, _i, _p],
     'vae_gauss_kl_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i, _p],
     'vae_gauss_kl_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
+    'vae_gumbel_fwd': [_p, _i64, _p, _p, _p, _p, _i64, _i64, _f, _u64, _u64, _i64, _i, _p],
+    'vae_gumbel_bwd': [_p, _p, _p, _p, _p, _p, _i64, _i64, _f, _i, _p],
+    'vae_categorical_kl_fwd': [_p, _i64, _p, _i64, _p, _i64, _i64, _i, _p],
+    'vae_categorical_kl_bwd': [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _p],
+    'vae_bernoulli_fwd': [_p, _i64, _p, _p, _p, _i64, _i64, _f, _u64, _u64, _i64, _i, _p],
+    'vae_bernoulli_bwd': [_p, _i64, _p, _p, _p, _p, _i64, _i64, _f, _i, _p],
+    'vae_bernoulli_kl_fwd': [_p, _i64, _p, _i64, _p, _i64, _i64, _i, _p],
+    'vae_bernoulli_kl_bwd': [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _p],
+    'vae_beta_split_kl_fwd': [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _f, _i, _p],
+    'vae_beta_split_kl_bwd': [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _f, _i, _p],
+    'vae_beta_kl_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i, _p],
+    'vae_beta_kl_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
+    'vae_flow_kl_fwd': [_p, _p, _i64, _p, _p, _p, _i64, _i64, _f, _i, _i, _i, _p],
+    'vae_flow_kl_bwd': [_p, _p, _p, _p, _i64, _i64, _f, _i, _p],
     'vae_nll_elbo_fwd': [_p, _p, _i, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
     'vae_nll_elbo_bwd': [_p, _p, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i64, _i, _p],
     'vae_elbo_combine_fwd': [_p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i, _p],

@@ -52,6 +52,10 @@ __device__ __forceinline__ float add_rn(float a, float b) {
 #pragma clang fp contract(off)
   return a + b;
 }
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
 __device__ __forceinline__ float div_rn(float a, float b) {
 #pragma clang fp contract(off)
   return a / b;
@@ -167,6 +171,34 @@ __device__ __forceinline__ float group_max(float v, int G) {
   return v;
 }
 __device__ __forceinline__ float wave_sum(float v) { return group_sum(v, 64); }
+
+// Row reductions for either geometry.  G <= 64: butterfly inside the lane group.  G == kBlock:
+// the whole block owns the row (wave butterfly, then LDS across the four waves); every thread of
+// the block must reach the call (uniform control flow).  All lanes get the result.
+__device__ __forceinline__ float row_sum(float v, int G) {
+  if (G <= 64) return group_sum(v, G);
+  __shared__ float lds_s[kBlock / 64];
+  v = group_sum(v, 64);
+  __syncthreads();  // the previous reduction's readers are done
+  if ((threadIdx.x & 63) == 0) lds_s[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) s += lds_s[w];
+  return s;
+}
+__device__ __forceinline__ float row_max(float v, int G) {
+  if (G <= 64) return group_max(v, G);
+  __shared__ float lds_m[kBlock / 64];
+  v = group_max(v, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds_m[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = lds_m[0];
+#pragma unroll
+  for (int w = 1; w < kBlock / 64; ++w) s = fmaxf(s, lds_m[w]);
+  return s;
+}
 
 // Block-level sum of N per-thread accumulators -> partials[blockIdx.x * N + k].
 // Fixed order (lane butterfly, then waves 0..3), so results are reproducible.
@@ -308,6 +340,26 @@ inline RowGeom row_geom(int64_t rows, int64_t vecs_per_row, int64_t max_grid = k
   g.grid = (int)(g.tiles < max_grid ? g.tiles : max_grid);
   if (g.grid < 1) g.grid = 1;
   return g;
+}
+
+// Geometry for kernels that keep a whole row in registers (softmax-class: several reductions over
+// the same row): the smallest lane group G (<= 64, else the whole block) with ceil(vecs/G) <= 4.
+// Returns false when the row does not fit (vecs > 4 * kBlock).
+inline bool row_geom_resident(int64_t rows, int64_t vecs_per_row, int64_t max_grid, RowGeom* out) {
+  if (vecs_per_row > 4 * kBlock) return false;
+  RowGeom g;
+  int G = 1;
+  while (G < 64 && (int64_t)G * 4 < vecs_per_row) G <<= 1;
+  if ((int64_t)G * 4 < vecs_per_row) G = kBlock;
+  g.G = G;
+  const int64_t iters = (vecs_per_row + G - 1) / G;
+  g.U = iters >= 3 ? 4 : (iters == 2 ? 2 : 1);
+  g.rows_per_block = kBlock / G;
+  g.tiles = (rows + g.rows_per_block - 1) / g.rows_per_block;
+  g.grid = (int)(g.tiles < max_grid ? g.tiles : max_grid);
+  if (g.grid < 1) g.grid = 1;
+  *out = g;
+  return true;
 }
 
 // Instantiate `...` with a constexpr U matching the runtime geometry.

@@ -83,21 +83,6 @@ __device__ __forceinline__ void nll_dlog_grad(float x, float a, float v, float& 
   gv = (dp * (-tp) + dm * (-t)) * inside;
 }
 
-// Row reduction for either geometry.  G <= 64: butterfly inside the lane group.
-// G == kBlock: the whole block owns the row (uniform control flow required).
-__device__ __forceinline__ float row_sum(float v, int G) {
-  if (G <= 64) return group_sum(v, G);
-  __shared__ float lds[kBlock / 64];
-  v = wave_sum(v);
-  __syncthreads();  // protect lds from the previous row's readers
-  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float s = 0.f;
-#pragma unroll
-  for (int w = 0; w < kBlock / 64; ++w) s += lds[w];
-  return s;
-}
-
 // ---------------------------------------------------------------------------
 // forward: nll[B] (+ loss[B], elbo[B], block partials of the six sums)
 // ---------------------------------------------------------------------------

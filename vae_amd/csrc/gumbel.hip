@@ -1,0 +1,388 @@
+// Gumbel-softmax sample (soft + straight-through hard) and the categorical KL, fused.
+//
+// Replaces the op chains of /root/reference reparameterizers/gumbel.py:
+//   :119      log_q_z = log_softmax(logits)
+//   :269-271  U = torch.rand (on the CPU, then an H2D copy of [B,K] every step);
+//             g = -log(-log(U + 1e-9) + 1e-9)
+//   :276-277  y = softmax((logits + g)/tau + 1e-9)
+//   :296-301  h = (y == rowmax(y))  (multi-hot on ties);  z_hard = (h - y).detach() + y
+//   :222-254  KL = sum softmax(a) * (log_softmax(a) - log_softmax(b)), a/b = log_q_z of q / prior
+//
+// The whole row lives in registers (K <= 4 * 256 vectors): one read of logits and U, one write
+// of y, z_hard and log_q_z -- 20K + 4 bytes per sample instead of ~10 launches over [B,K].
+// The hard mask is computed from y exactly as the reference does (same op order: x - max, exp,
+// times 1/sum as ATen's CPU softmax, == rowmax), so ties give the same multi-hot rows.
+#include "common.hpp"
+#include "../../include/vae_amd.h"
+
+namespace vae {
+
+constexpr float kGumbelEps = 1e-9f;
+constexpr float kNegInf = -3.402823466e+38f;
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+template <typename T, int V, int U>
+__global__ __launch_bounds__(kBlock) void gumbel_fwd_kernel(
+    const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ unif, T* __restrict__ y_out,
+    T* __restrict__ zh_out, T* __restrict__ lq_out, int64_t B, int K, float tau, uint64_t seed, uint64_t offset,
+    int64_t row0, int G, int64_t tiles) {
+  const int rpb = kBlock / G;
+  const int sub = threadIdx.x % G;
+  const int rloc = threadIdx.x / G;
+  const int nvec = K / V;
+
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t row = t * rpb + rloc;
+    const bool live = row < B;
+    const int64_t r = live ? row : B - 1;  // dead lane groups shadow the last row (no stores)
+    float l[U][V], u[U][V];
+    load_chunk<T, V, U>(logits + r * row_stride, sub, G, nvec, l);
+    if (unif) load_chunk<T, V, U>(unif + r * K, sub, G, nvec, u);
+
+    // ---- log_q_z = (l - max) - log(sum exp(l - max))
+    float m1 = kNegInf;
+#pragma unroll
+    for (int k = 0; k < U; ++k)
+      if (sub + k * G < nvec)
+#pragma unroll
+        for (int i = 0; i < V; ++i) m1 = fmaxf(m1, l[k][i]);
+    m1 = row_max(m1, G);
+    float s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < U; ++k)
+      if (sub + k * G < nvec)
+#pragma unroll
+        for (int i = 0; i < V; ++i) s1 += expf(sub_rn(l[k][i], m1));
+    s1 = row_sum(s1, G);
+    const float lse = logf(s1);
+
+    // ---- x = (l + g)/tau + eps, g = -log(-log(U + eps) + eps): every op rounds on its own
+    float x[U][V];
+    float m2 = kNegInf;
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int j = sub + k * G;
+      if (j < nvec) {
+        if (!unif) philox_uniform<V>(seed, offset, (uint64_t)(row0 + r) * (uint64_t)K + (uint64_t)j * V, u[k]);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          float g = -logf(add_rn(u[k][i], kGumbelEps));
+          g = -logf(add_rn(g, kGumbelEps));
+          g = to_f32(from_f32<T>(g));
+          const float xi = to_f32(from_f32<T>(div_rn(to_f32(from_f32<T>(add_rn(l[k][i], g))), tau)));
+          x[k][i] = to_f32(from_f32<T>(add_rn(xi, kGumbelEps)));
+          m2 = fmaxf(m2, x[k][i]);
+        }
+      }
+    }
+    m2 = row_max(m2, G);
+    float s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < U; ++k)
+      if (sub + k * G < nvec)
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          x[k][i] = expf(sub_rn(x[k][i], m2));
+          s2 += x[k][i];
+        }
+    s2 = row_sum(s2, G);
+    const float rinv = div_rn(1.0f, s2);  // ATen's CPU softmax multiplies by the reciprocal
+    float ymax = 0.f;
+#pragma unroll
+    for (int k = 0; k < U; ++k)
+      if (sub + k * G < nvec)
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          x[k][i] = to_f32(from_f32<T>(mul_rn(x[k][i], rinv)));
+          ymax = fmaxf(ymax, x[k][i]);
+        }
+    ymax = row_max(ymax, G);
+
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int j = sub + k * G;
+        if (j < nvec) {
+          float zh[V], lq[V];
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            const float h = (x[k][i] == ymax) ? 1.0f : 0.0f;
+            zh[i] = add_rn(to_f32(from_f32<T>(sub_rn(h, x[k][i]))), x[k][i]);  // (h - y).detach() + y
+            lq[i] = sub_rn(sub_rn(l[k][i], m1), lse);
+          }
+          store_vec<T, V>(y_out + row * K + (int64_t)j * V, x[k]);
+          store_vec<T, V>(zh_out + row * K + (int64_t)j * V, zh);
+          store_vec<T, V>(lq_out + row * K + (int64_t)j * V, lq);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// backward: g_logits = (1/tau) * y * (gt - sum(gt*y)) + (glq - exp(lq) * sum(glq)),
+// gt = gy + gzh (the straight-through hard sample passes its gradient to y unchanged)
+// ---------------------------------------------------------------------------
+template <typename T, int V, int U>
+__global__ __launch_bounds__(kBlock) void gumbel_bwd_kernel(
+    const T* __restrict__ y, const T* __restrict__ lq, const T* __restrict__ gy, const T* __restrict__ gzh,
+    const T* __restrict__ glq, T* __restrict__ glogits, int64_t B, int K, float tau, int G, int64_t tiles) {
+  const int rpb = kBlock / G;
+  const int sub = threadIdx.x % G;
+  const int rloc = threadIdx.x / G;
+  const int nvec = K / V;
+  const float itau = 1.0f / tau;
+
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t row = t * rpb + rloc;
+    const bool live = row < B;
+    const int64_t r = live ? row : B - 1;
+    float yv[U][V], gt[U][V], q[U][V], gq[U][V];
+    const bool soft = gy || gzh;
+    if (soft) load_chunk<T, V, U>(y + r * K, sub, G, nvec, yv);
+    if (gy) load_chunk<T, V, U>(gy + r * K, sub, G, nvec, gt);
+    if (gzh) load_chunk<T, V, U>(gzh + r * K, sub, G, nvec, q);
+    if (gy && gzh) {
+#pragma unroll
+      for (int k = 0; k < U; ++k)
+#pragma unroll
+        for (int i = 0; i < V; ++i) gt[k][i] += q[k][i];
+    } else if (gzh) {
+#pragma unroll
+      for (int k = 0; k < U; ++k)
+#pragma unroll
+        for (int i = 0; i < V; ++i) gt[k][i] = q[k][i];
+    }
+    if (glq) {
+      load_chunk<T, V, U>(lq + r * K, sub, G, nvec, q);
+      load_chunk<T, V, U>(glq + r * K, sub, G, nvec, gq);
+    }
+    float dot = 0.f, sg = 0.f;
+#pragma unroll
+    for (int k = 0; k < U; ++k)
+      if (sub + k * G < nvec)
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          if (soft) dot += gt[k][i] * yv[k][i];
+          if (glq) sg += gq[k][i];
+        }
+    if (soft) dot = row_sum(dot, G);
+    if (glq) sg = row_sum(sg, G);
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int j = sub + k * G;
+        if (j < nvec) {
+          float o[V];
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            float v = 0.f;
+            if (soft) v += itau * yv[k][i] * (gt[k][i] - dot);
+            if (glq) v += gq[k][i] - expf(q[k][i]) * sg;
+            o[i] = v;
+          }
+          store_vec<T, V>(glogits + row * K + (int64_t)j * V, o);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// categorical KL: kl = sum_k p_k (la_k - lb_k), la = log_softmax(a), lb = log_softmax(b), p = exp(la).
+// OneHotCategorical(logits=.) normalises once more (logits - logsumexp): idempotent up to
+// rounding on an already normalised log_q_z, folded into the one log_softmax here.
+// ---------------------------------------------------------------------------
+template <typename T, int V, int U>
+__device__ __forceinline__ void row_log_softmax(float (&a)[U][V], int sub, int G, int nvec) {
+  float m = kNegInf;
+#pragma unroll
+  for (int k = 0; k < U; ++k)
+    if (sub + k * G < nvec)
+#pragma unroll
+      for (int i = 0; i < V; ++i) m = fmaxf(m, a[k][i]);
+  m = row_max(m, G);
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < U; ++k)
+    if (sub + k * G < nvec)
+#pragma unroll
+      for (int i = 0; i < V; ++i) s += expf(a[k][i] - m);
+  s = row_sum(s, G);
+  const float lse = m + logf(s);
+#pragma unroll
+  for (int k = 0; k < U; ++k)
+#pragma unroll
+    for (int i = 0; i < V; ++i) a[k][i] -= lse;
+}
+
+template <typename T, int V, int U, bool BWD>
+__global__ __launch_bounds__(kBlock) void categorical_kl_kernel(
+    const T* __restrict__ a, int64_t stride_a, const T* __restrict__ b, int64_t stride_b, const T* __restrict__ gkl,
+    T* __restrict__ kl, T* __restrict__ ga, T* __restrict__ gb, int64_t B, int K, int G, int64_t tiles) {
+  const int rpb = kBlock / G;
+  const int sub = threadIdx.x % G;
+  const int rloc = threadIdx.x / G;
+  const int nvec = K / V;
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t row = t * rpb + rloc;
+    const bool live = row < B;
+    const int64_t r = live ? row : B - 1;
+    float la[U][V], lb[U][V];
+    load_chunk<T, V, U>(a + r * stride_a, sub, G, nvec, la);
+    load_chunk<T, V, U>(b + r * stride_b, sub, G, nvec, lb);
+    row_log_softmax<T, V, U>(la, sub, G, nvec);
+    row_log_softmax<T, V, U>(lb, sub, G, nvec);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < U; ++k)
+      if (sub + k * G < nvec)
+#pragma unroll
+        for (int i = 0; i < V; ++i) s += expf(la[k][i]) * (la[k][i] - lb[k][i]);
+    s = row_sum(s, G);
+    if (!live) continue;
+    if constexpr (!BWD) {
+      if (sub == 0) kl[row] = from_f32<T>(s);
+    } else {
+      const float gk = to_f32(gkl[row]);
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int j = sub + k * G;
+        if (j < nvec) {
+          float oa[V], ob[V];
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            const float p = expf(la[k][i]);
+            oa[i] = gk * p * ((la[k][i] - lb[k][i]) - s);
+            ob[i] = gk * (expf(lb[k][i]) - p);
+          }
+          store_vec<T, V>(ga + row * K + (int64_t)j * V, oa);
+          if (gb) store_vec<T, V>(gb + row * K + (int64_t)j * V, ob);
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+static int gumbel_fwd_dispatch(const void* logits, int64_t row_stride, const void* unif, void* y, void* zh, void* lq,
+                               int64_t B, int64_t K, float tau, uint64_t seed, uint64_t offset, int64_t row0,
+                               hipStream_t stream) {
+  constexpr int VN = VecOf<T>::n;
+  const bool vec = (K % VN == 0) && (row_stride % VN == 0) && aligned16(logits) && aligned16(y) && aligned16(zh) &&
+                   aligned16(lq) && (!unif || aligned16(unif));
+  RowGeom g;
+  if (!row_geom_resident(B, vec ? K / VN : K, kGridStream, &g)) return VAE_ERR_ARG;
+  if (vec) {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gumbel_fwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
+                                         (const T*)logits, row_stride, (const T*)unif, (T*)y, (T*)zh, (T*)lq, B,
+                                         (int)K, tau, seed, offset, row0, g.G, g.tiles));
+  } else {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gumbel_fwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, stream,
+                                         (const T*)logits, row_stride, (const T*)unif, (T*)y, (T*)zh, (T*)lq, B,
+                                         (int)K, tau, seed, offset, row0, g.G, g.tiles));
+  }
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+template <typename T>
+static int gumbel_bwd_dispatch(const void* y, const void* lq, const void* gy, const void* gzh, const void* glq,
+                               void* glogits, int64_t B, int64_t K, float tau, hipStream_t stream) {
+  constexpr int VN = VecOf<T>::n;
+  const bool vec = (K % VN == 0) && aligned16(y) && aligned16(lq) && aligned16(glogits) && (!gy || aligned16(gy)) &&
+                   (!gzh || aligned16(gzh)) && (!glq || aligned16(glq));
+  RowGeom g;
+  if (!row_geom_resident(B, vec ? K / VN : K, kGridStream, &g)) return VAE_ERR_ARG;
+  if (vec) {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gumbel_bwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
+                                         (const T*)y, (const T*)lq, (const T*)gy, (const T*)gzh, (const T*)glq,
+                                         (T*)glogits, B, (int)K, tau, g.G, g.tiles));
+  } else {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gumbel_bwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, stream,
+                                         (const T*)y, (const T*)lq, (const T*)gy, (const T*)gzh, (const T*)glq,
+                                         (T*)glogits, B, (int)K, tau, g.G, g.tiles));
+  }
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+template <typename T, bool BWD>
+static int cat_kl_dispatch(const void* a, int64_t sa, const void* b, int64_t sb, const void* gkl, void* kl, void* ga,
+                           void* gb, int64_t B, int64_t K, hipStream_t stream) {
+  constexpr int VN = VecOf<T>::n;
+  bool vec = (K % VN == 0) && (sa % VN == 0) && (sb % VN == 0) && aligned16(a) && aligned16(b);
+  if (BWD) vec = vec && aligned16(ga) && (!gb || aligned16(gb));
+  RowGeom g;
+  if (!row_geom_resident(B, vec ? K / VN : K, kGridStream, &g)) return VAE_ERR_ARG;
+  if (vec) {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((categorical_kl_kernel<T, VN, U, BWD>), dim3(g.grid), dim3(kBlock), 0,
+                                         stream, (const T*)a, sa, (const T*)b, sb, (const T*)gkl, (T*)kl, (T*)ga,
+                                         (T*)gb, B, (int)K, g.G, g.tiles));
+  } else {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((categorical_kl_kernel<T, 1, U, BWD>), dim3(g.grid), dim3(kBlock), 0, stream,
+                                         (const T*)a, sa, (const T*)b, sb, (const T*)gkl, (T*)kl, (T*)ga, (T*)gb, B,
+                                         (int)K, g.G, g.tiles));
+  }
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+}  // namespace vae
+
+using namespace vae;
+
+extern "C" {
+
+int vae_gumbel_fwd(const void* logits, int64_t row_stride, const void* unif, void* y, void* z_hard, void* log_q_z,
+                   int64_t B, int64_t K, float tau, uint64_t seed, uint64_t offset, int64_t row0, int dtype,
+                   vae_stream_t stream) {
+  if (B < 0 || K <= 0 || K > VAE_MAX_SOFTMAX_ROW || !(tau > 0.f)) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  if (!logits || !y || !z_hard || !log_q_z || row_stride < K) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VAE_F32)
+    return gumbel_fwd_dispatch<float>(logits, row_stride, unif, y, z_hard, log_q_z, B, K, tau, seed, offset, row0, st);
+  if (dtype == VAE_BF16)
+    return gumbel_fwd_dispatch<bf16_t>(logits, row_stride, unif, y, z_hard, log_q_z, B, K, tau, seed, offset, row0,
+                                       st);
+  return VAE_ERR_ARG;
+}
+
+int vae_gumbel_bwd(const void* y, const void* log_q_z, const void* gy, const void* gz_hard, const void* glog_q_z,
+                   void* glogits, int64_t B, int64_t K, float tau, int dtype, vae_stream_t stream) {
+  if (B < 0 || K <= 0 || K > VAE_MAX_SOFTMAX_ROW || !(tau > 0.f)) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  if (!y || !log_q_z || !glogits) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VAE_F32) return gumbel_bwd_dispatch<float>(y, log_q_z, gy, gz_hard, glog_q_z, glogits, B, K, tau, st);
+  if (dtype == VAE_BF16) return gumbel_bwd_dispatch<bf16_t>(y, log_q_z, gy, gz_hard, glog_q_z, glogits, B, K, tau, st);
+  return VAE_ERR_ARG;
+}
+
+int vae_categorical_kl_fwd(const void* log_q, int64_t stride_q, const void* log_p, int64_t stride_p, void* kl,
+                           int64_t B, int64_t K, int dtype, vae_stream_t stream) {
+  if (B < 0 || K <= 0 || K > VAE_MAX_SOFTMAX_ROW) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  if (!log_q || !log_p || !kl || stride_q < K || stride_p < K) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VAE_F32)
+    return cat_kl_dispatch<float, false>(log_q, stride_q, log_p, stride_p, nullptr, kl, nullptr, nullptr, B, K, st);
+  if (dtype == VAE_BF16)
+    return cat_kl_dispatch<bf16_t, false>(log_q, stride_q, log_p, stride_p, nullptr, kl, nullptr, nullptr, B, K, st);
+  return VAE_ERR_ARG;
+}
+
+int vae_categorical_kl_bwd(const void* log_q, int64_t stride_q, const void* log_p, int64_t stride_p, const void* gkl,
+                           void* g_log_q, void* g_log_p, int64_t B, int64_t K, int dtype, vae_stream_t stream) {
+  if (B < 0 || K <= 0 || K > VAE_MAX_SOFTMAX_ROW) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  if (!log_q || !log_p || !gkl || !g_log_q || stride_q < K || stride_p < K) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VAE_F32)
+    return cat_kl_dispatch<float, true>(log_q, stride_q, log_p, stride_p, gkl, nullptr, g_log_q, g_log_p, B, K, st);
+  if (dtype == VAE_BF16)
+    return cat_kl_dispatch<bf16_t, true>(log_q, stride_q, log_p, stride_p, gkl, nullptr, g_log_q, g_log_p, B, K, st);
+  return VAE_ERR_ARG;
+}
+
+}  // extern "C"

@@ -262,3 +262,310 @@ def elbo_combine(nll_, kld=None, add=None, mi=None, kl_beta=1.0, inv_count=None)
     if inv_count is None:
         inv_count = 1.0 / max(nll_.shape[0], 1)
     return _ElboCombine.apply(nll_, _dense(kld), _dense(add), _dense(mi), float(kl_beta), float(inv_count))
+
+
+# --------------------------------------------------------------------------------------
+# GumbelSoftmax
+# --------------------------------------------------------------------------------------
+class _Gumbel(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, unif, tau, seed, offset, row0):
+        ctx.set_materialize_grads(False)
+        dev = check_device(logits, unif)
+        B, K = logits.shape
+        y = torch.empty((B, K), dtype=logits.dtype, device=dev)
+        zh = torch.empty_like(y)
+        lq = torch.empty_like(y)
+        with _Guard(dev):
+            call('vae_gumbel_fwd', ptr(logits), logits.stride(0), ptr(unif), ptr(y), ptr(zh), ptr(lq), B, K, tau,
+                 seed & _MASK64, offset & _MASK64, row0, dtype_code(logits), stream_ptr(dev))
+        ctx.save_for_backward(y, lq)
+        ctx.tau = tau
+        return y, zh, lq
+
+    @staticmethod
+    def backward(ctx, gy, gzh, glq):
+        if gy is None and gzh is None and glq is None:
+            return None, None, None, None, None, None
+        y, lq = ctx.saved_tensors
+        dev = y.device
+        B, K = y.shape
+        gy, gzh, glq = _dense(gy), _dense(gzh), _dense(glq)
+        gl = torch.empty_like(y)
+        with _Guard(dev):
+            call('vae_gumbel_bwd', ptr(y), ptr(lq), ptr(gy), ptr(gzh), ptr(glq), ptr(gl), B, K, ctx.tau,
+                 dtype_code(y), stream_ptr(dev))
+        return gl, None, None, None, None, None
+
+
+def gumbel_softmax(logits, unif=None, tau=1.0, seed=0, offset=0, row0=0):
+    """logits [..., K] -> (y soft sample, z_hard straight-through, log_q_z), all [..., K].
+
+    Reference: reparameterizers/gumbel.py:110-124, :257-304.  `unif` is the torch.rand draw of :269
+    (None: Philox in the kernel)."""
+    shape = logits.shape
+    rows = _rows(logits)
+    if unif is not None:
+        unif = unif.reshape(rows.shape).to(rows.dtype).contiguous()
+    y, zh, lq = _Gumbel.apply(rows, unif, float(tau), int(seed), int(offset), int(row0))
+    return y.reshape(shape), zh.reshape(shape), lq.reshape(shape)
+
+
+class _CategoricalKL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lq, lp):
+        ctx.set_materialize_grads(False)
+        dev = check_device(lq, lp)
+        B, K = lq.shape
+        kl = torch.empty((B,), dtype=lq.dtype, device=dev)
+        with _Guard(dev):
+            call('vae_categorical_kl_fwd', ptr(lq), lq.stride(0), ptr(lp), lp.stride(0), ptr(kl), B, K,
+                 dtype_code(lq), stream_ptr(dev))
+        ctx.save_for_backward(lq, lp)
+        return kl
+
+    @staticmethod
+    def backward(ctx, gkl):
+        if gkl is None:
+            return None, None
+        lq, lp = ctx.saved_tensors
+        dev = lq.device
+        B, K = lq.shape
+        gq = torch.empty((B, K), dtype=lq.dtype, device=dev)
+        gp = torch.empty_like(gq) if ctx.needs_input_grad[1] else None
+        with _Guard(dev):
+            call('vae_categorical_kl_bwd', ptr(lq), lq.stride(0), ptr(lp), lp.stride(0), ptr(gkl.contiguous()),
+                 ptr(gq), ptr(gp), B, K, dtype_code(lq), stream_ptr(dev))
+        return gq, gp
+
+
+def categorical_kl(log_q, log_p):
+    """sum softmax(q) * (log_softmax(q) - log_softmax(p)) over the last dim (gumbel.py:222-254)."""
+    shape = log_q.shape[:-1]
+    return _CategoricalKL.apply(_rows(log_q), _rows(log_p.expand_as(log_q))).reshape(shape)
+
+
+# --------------------------------------------------------------------------------------
+# Bernoulli (relaxed)
+# --------------------------------------------------------------------------------------
+class _Bernoulli(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, unif, tau, seed, offset, row0):
+        ctx.set_materialize_grads(False)
+        dev = check_device(logits, unif)
+        B, K = logits.shape
+        y = torch.empty((B, K), dtype=logits.dtype, device=dev)
+        zh = torch.empty_like(y)
+        with _Guard(dev):
+            call('vae_bernoulli_fwd', ptr(logits), logits.stride(0), ptr(unif), ptr(y), ptr(zh), B, K, tau,
+                 seed & _MASK64, offset & _MASK64, row0, dtype_code(logits), stream_ptr(dev))
+        ctx.save_for_backward(logits, y)
+        ctx.tau = tau
+        return y, zh
+
+    @staticmethod
+    def backward(ctx, gy, gzh):
+        if gy is None and gzh is None:
+            return None, None, None, None, None, None
+        logits, y = ctx.saved_tensors
+        dev = y.device
+        B, K = y.shape
+        gl = torch.empty_like(y)
+        with _Guard(dev):
+            call('vae_bernoulli_bwd', ptr(logits), logits.stride(0), ptr(y), ptr(_dense(gy)), ptr(_dense(gzh)),
+                 ptr(gl), B, K, ctx.tau, dtype_code(y), stream_ptr(dev))
+        return gl, None, None, None, None, None
+
+
+def relaxed_bernoulli(logits, unif=None, tau=1.0, seed=0, offset=0, row0=0):
+    """logits [..., K] -> (y relaxed sample, z_hard straight-through).  bernoulli.py:111-136."""
+    shape = logits.shape
+    rows = _rows(logits)
+    if unif is not None:
+        unif = unif.reshape(rows.shape).to(rows.dtype).contiguous()
+    y, zh = _Bernoulli.apply(rows, unif, float(tau), int(seed), int(offset), int(row0))
+    return y.reshape(shape), zh.reshape(shape)
+
+
+class _BernoulliKL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lq, lp):
+        ctx.set_materialize_grads(False)
+        dev = check_device(lq, lp)
+        B, K = lq.shape
+        kl = torch.empty((B,), dtype=lq.dtype, device=dev)
+        with _Guard(dev):
+            call('vae_bernoulli_kl_fwd', ptr(lq), lq.stride(0), ptr(lp), 0 if lp is None else lp.stride(0), ptr(kl),
+                 B, K, dtype_code(lq), stream_ptr(dev))
+        ctx.save_for_backward(lq, lp)
+        return kl
+
+    @staticmethod
+    def backward(ctx, gkl):
+        if gkl is None:
+            return None, None
+        lq, lp = ctx.saved_tensors
+        dev = lq.device
+        B, K = lq.shape
+        gq = torch.empty((B, K), dtype=lq.dtype, device=dev)
+        gp = torch.empty_like(gq) if (lp is not None and ctx.needs_input_grad[1]) else None
+        with _Guard(dev):
+            call('vae_bernoulli_kl_bwd', ptr(lq), lq.stride(0), ptr(lp), 0 if lp is None else lp.stride(0),
+                 ptr(gkl.contiguous()), ptr(gq), ptr(gp), B, K, dtype_code(lq), stream_ptr(dev))
+        return gq, gp
+
+
+def bernoulli_kl(logits_q, logits_p=None):
+    """bernoulli.py:147-191 summed over the last dim; logits_p None = uniform prior (p = 0.5)."""
+    shape = logits_q.shape[:-1]
+    lp = None if logits_p is None else _rows(logits_p.expand_as(logits_q))
+    return _BernoulliKL.apply(_rows(logits_q), lp).reshape(shape)
+
+
+# --------------------------------------------------------------------------------------
+# Beta
+# --------------------------------------------------------------------------------------
+class _BetaSplitKL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, mean_scale):
+        ctx.set_materialize_grads(False)
+        dev = check_device(logits)
+        B, L = logits.shape[0], logits.shape[1] // 2
+        c1 = torch.empty((B, L), dtype=logits.dtype, device=dev)
+        c0 = torch.empty_like(c1)
+        kl = torch.empty((B,), dtype=logits.dtype, device=dev)
+        means = torch.zeros((2,), dtype=torch.float32, device=dev)
+        if mean_scale is None:
+            mean_scale = 1.0 / max(B * L, 1)
+        with _Guard(dev):
+            call('vae_beta_split_kl_fwd', ptr(logits), logits.stride(0), ptr(c1), ptr(c0), ptr(kl), ptr(means),
+                 ptr(workspace(dev)), B, L, mean_scale, dtype_code(logits), stream_ptr(dev))
+        ctx.save_for_backward(logits)
+        ctx.mean_scale = mean_scale
+        return c1, c0, kl, means
+
+    @staticmethod
+    def backward(ctx, g1, g0, gkl, gmeans):
+        (logits,) = ctx.saved_tensors
+        dev = logits.device
+        B, L = logits.shape[0], logits.shape[1] // 2
+        gmeans = None if gmeans is None else gmeans.contiguous().float()
+        gl = torch.empty((B, 2 * L), dtype=logits.dtype, device=dev)
+        with _Guard(dev):
+            call('vae_beta_split_kl_bwd', ptr(logits), logits.stride(0), ptr(_dense(g1)), ptr(_dense(g0)),
+                 ptr(_dense(gkl)), ptr(gmeans), ptr(gl), B, L, ctx.mean_scale, dtype_code(logits), stream_ptr(dev))
+        return gl, None
+
+
+def beta_split_kl(logits, mean_scale=None):
+    """logits [B, 2L] -> (conc1, conc2 [B, L], kl vs Beta(1.1,1.1) [B], means float32[2]).  beta.py:105-124."""
+    return _BetaSplitKL.apply(_rows(logits), mean_scale)
+
+
+class _BetaKL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a1, a0, b1, b0):
+        ctx.set_materialize_grads(False)
+        dev = check_device(a1, a0, b1, b0)
+        B, L = a1.shape
+        kl = torch.empty((B,), dtype=a1.dtype, device=dev)
+        sb1 = 0 if b1 is None else b1.stride(0)
+        sb0 = 0 if b0 is None else b0.stride(0)
+        with _Guard(dev):
+            call('vae_beta_kl_fwd', ptr(a1), a1.stride(0), ptr(a0), a0.stride(0), ptr(b1), sb1, ptr(b0), sb0,
+                 ptr(kl), B, L, dtype_code(a1), stream_ptr(dev))
+        ctx.save_for_backward(a1, a0, b1, b0)
+        return kl
+
+    @staticmethod
+    def backward(ctx, gkl):
+        if gkl is None:
+            return None, None, None, None
+        a1, a0, b1, b0 = ctx.saved_tensors
+        dev = a1.device
+        B, L = a1.shape
+        ga1 = torch.empty((B, L), dtype=a1.dtype, device=dev)
+        ga0 = torch.empty_like(ga1)
+        need_p = b1 is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        gb1 = torch.empty_like(ga1) if need_p else None
+        gb0 = torch.empty_like(ga1) if need_p else None
+        sb1 = 0 if b1 is None else b1.stride(0)
+        sb0 = 0 if b0 is None else b0.stride(0)
+        with _Guard(dev):
+            call('vae_beta_kl_bwd', ptr(a1), a1.stride(0), ptr(a0), a0.stride(0), ptr(b1), sb1, ptr(b0), sb0,
+                 ptr(gkl.contiguous()), ptr(ga1), ptr(ga0), ptr(gb1), ptr(gb0), B, L, dtype_code(a1), stream_ptr(dev))
+        return ga1, ga0, gb1, gb0
+
+
+def beta_kl(a1, a0, b1=None, b0=None):
+    """KL(Beta(a1, a0) || Beta(b1, b0) or Beta(1.1, 1.1)) over the last dim.  beta.py:110-136."""
+    shape = a1.shape[:-1]
+    args = [_rows(a1), _rows(a0), None, None]
+    if b1 is not None:
+        args[2], args[3] = _rows(b1.expand_as(a1)), _rows(b0.expand_as(a0))
+    return _BetaKL.apply(*args).reshape(shape)
+
+
+# --------------------------------------------------------------------------------------
+# Flow "KL"
+# --------------------------------------------------------------------------------------
+class _FlowKL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, logdet, inv_count, reduce_fn):
+        ctx.set_materialize_grads(False)
+        dev = check_device(u, logdet)
+        cross = u.dim() == 2
+        if cross:
+            B, F = u.shape
+            R = 1
+        else:
+            B, R, F = u.shape
+        kl = torch.empty((B,), dtype=u.dtype, device=dev)
+        mean = torch.zeros((1,), dtype=torch.float32, device=dev)
+        if inv_count is None:
+            inv_count = 1.0 / max(B, 1)
+        args = (ptr(u), ptr(logdet), R, ptr(kl), ptr(mean), ptr(workspace(dev)), B, F, inv_count, int(cross))
+        with _Guard(dev):
+            if cross and reduce_fn is not None:
+                call('vae_flow_kl_fwd', *args, 1, dtype_code(u), stream_ptr(dev))
+                reduce_fn(mean)                      # sharded batch: all-reduce(sum) of the partial mean
+                call('vae_flow_kl_fwd', *args, 2, dtype_code(u), stream_ptr(dev))
+            else:
+                call('vae_flow_kl_fwd', *args, 0, dtype_code(u), stream_ptr(dev))
+        ctx.save_for_backward(u)
+        ctx.cfg = (cross, B, R, F, inv_count, reduce_fn, logdet.shape)
+        return kl
+
+    @staticmethod
+    def backward(ctx, gkl):
+        if gkl is None:
+            return None, None, None, None
+        (u,) = ctx.saved_tensors
+        cross, B, R, F, inv_count, reduce_fn, ld_shape = ctx.cfg
+        dev = u.device
+        gkl = gkl.contiguous()
+        gu = torch.empty_like(u) if ctx.needs_input_grad[0] else None
+        if gu is not None:
+            with _Guard(dev):
+                if cross:
+                    gsum = gkl.float().sum().reshape(1)
+                    if reduce_fn is not None:
+                        reduce_fn(gsum)
+                    call('vae_flow_kl_bwd', ptr(u), None, ptr(gsum), ptr(gu), B, F, inv_count, dtype_code(u),
+                         stream_ptr(dev))
+                else:
+                    call('vae_flow_kl_bwd', ptr(u), ptr(gkl), None, ptr(gu), B, R * F, 1.0 / R, dtype_code(u),
+                         stream_ptr(dev))
+        gld = None
+        if ctx.needs_input_grad[1]:
+            gld = (-gkl).reshape(B, 1).expand(B, R).reshape(ld_shape) if cross else \
+                (-gkl / R).reshape(B, 1).expand(B, R).reshape(ld_shape)
+        return gu, gld, None, None
+
+
+def flow_kl(u, logdet, inv_count=None, reduce_fn=None):
+    """flow.py:67-78.  u [B,F] + logdet [B,1]: kl_i = mean_j(nlp_j) - logdet_i (the reference's [B,B]
+    broadcast, SURVEY Q6, in O(B*F)).  u [B,R,F] + logdet [B,R]: kl_i = mean_r(nlp_ir - logdet_ir)."""
+    if u.dim() == 2 and logdet.dim() == 2 and logdet.shape[1] != 1:
+        raise ValueError("flow_kl: 2-D recon_x needs logdet [B,1]")
+    return _FlowKL.apply(u.contiguous(), logdet.contiguous(), inv_count, reduce_fn)

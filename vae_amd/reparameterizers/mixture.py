@@ -1,0 +1,70 @@
+"""Mixture (continuous + discrete side by side), reference reparameterizers/mixture.py.
+
+The reference class is marked deprecated and cannot be constructed: its __init__ reads
+self.num_continuous / self.num_discrete, which are never set (mixture.py:16-27, SURVEY Q4;
+AttributeError).  This class keeps the interface and the evident intent (input_size =
+num_continuous_input + num_discrete_input) so that the 'mixture' registry entry and VRNN's
+`_clamp_variance` branch (vrnn.py:409-415) have something to call; its behaviour equals
+ConcatReparameterizer([continuous, 'discrete']) with the reference's mixture param-dict layout."""
+import torch
+import torch.nn as nn
+
+from .beta import Beta
+from .gumbel import GumbelSoftmax
+from .isotropic_gaussian import IsotropicGaussian
+
+
+class Mixture(nn.Module):
+    def __init__(self, config, is_beta=False):
+        super(Mixture, self).__init__()
+        self.config = config
+        self.is_beta = is_beta
+        self.is_discrete = False
+        self.continuous = IsotropicGaussian(config) if not is_beta else Beta(config)
+        self.discrete = GumbelSoftmax(config)
+        self.num_discrete_input = self.discrete.input_size
+        self.num_continuous_input = self.continuous.input_size
+        self.num_discrete_output = self.discrete.output_size
+        self.num_continuous_output = self.continuous.output_size
+        self.input_size = self.num_continuous_input + self.num_discrete_input
+        self.output_size = self.num_continuous_output + self.num_discrete_output
+
+    def get_reparameterizer_scalars(self):
+        return self.discrete.get_reparameterizer_scalars()
+
+    def prior_params(self, batch_size, **kwargs):
+        cont_params = self.continuous.prior_params(batch_size, **kwargs)
+        disc_params = self.discrete.prior_params(batch_size, **kwargs)
+        return {**disc_params, **cont_params}
+
+    def prior(self, batch_size, **kwargs):
+        disc = self.discrete.prior(batch_size, **kwargs)
+        cont = self.continuous.prior(batch_size, **kwargs)
+        return torch.cat([cont, disc.type(cont.dtype)], 1)
+
+    def mutual_info(self, params):
+        dinfo = self.discrete.mutual_info(params)
+        cinfo = self.continuous.mutual_info(params)
+        return dinfo - cinfo
+
+    def log_likelihood(self, z, params):
+        cont = self.continuous.log_likelihood(z[:, 0:self.continuous.output_size], params)
+        disc = self.discrete.log_likelihood(z[:, self.continuous.output_size:], params)
+        if disc.dim() < 2:
+            disc = disc.unsqueeze(-1)
+        return torch.cat([cont, disc], 1)
+
+    def forward(self, logits, force=False, noise=None):
+        noise = [None, None] if noise is None else noise
+        n_c = self.num_continuous_input
+        kw = {} if noise[0] is None else {'noise': noise[0]}
+        continuous, continuous_params = self.continuous(logits[:, 0:n_c], force=force, **kw)
+        kw = {} if noise[1] is None else {'noise': noise[1]}
+        discrete, disc_params = self.discrete(logits[:, n_c:], force=force, **kw)
+        merged = torch.cat([continuous, discrete], -1)
+        key = 'gaussian' if not self.is_beta else 'beta'
+        params = {'logits': logits, 'z': merged, key: continuous_params[key], 'discrete': disc_params['discrete']}
+        return merged, params
+
+    def kl(self, dist_a, prior=None):
+        return self.continuous.kl(dist_a, prior) + self.discrete.kl(dist_a, prior)

@@ -1,0 +1,88 @@
+"""The VRNN hot path with the reference's semantics (vrnn.py:395-447 reparameterize /
+_clamp_variance, :723-733 kld, :767-829 loss aggregation; additive_vrnn.py:78-104).
+
+The recurrence (LSTM, phi_x / phi_z / prior nets, decoder) is the host project's stock PyTorch;
+what is here is what runs per time step on its outputs: two reparameterizations (posterior first,
+then the variance-clamped prior), KL(posterior || prior) [+ KL(prior || N(0,1))], and the per-step
+ELBO dicts averaged over T.  `loss_function` scores all T steps in ONE fused NLL+ELBO launch over
+[T*B] rows instead of T Python-loop iterations of ~40 launches each; the result
+equals the reference's `_add_loss_map` / `_mean_map` because every step holds the same B samples.
+"""
+import torch
+
+from . import functional as F_
+from .elbo import _pack
+
+
+def clamp_variance(logits, config, reparameterizer=None):
+    """vrnn.py:395-417."""
+    if config['reparam_type'] == 'isotropic_gaussian':
+        feat_size = logits.size(-1)
+        return torch.cat([logits[:, 0:feat_size // 2], torch.sigmoid(logits[:, feat_size // 2:])], -1)
+    elif config['reparam_type'] == 'mixture':
+        feat_size = reparameterizer.num_continuous_input
+        return torch.cat([logits[:, 0:feat_size // 2], torch.sigmoid(logits[:, feat_size // 2:feat_size]),
+                          logits[:, feat_size:]], -1)
+    return logits
+
+
+def reparameterize(reparameterizer, logits_map, config, noise=None):
+    """vrnn.py:419-447.  `noise` = (posterior noise, prior noise) for injection, else in-kernel Philox;
+    both draws consume the generator in the reference's order (posterior first)."""
+    noise = (None, None) if noise is None else noise
+    kw = {} if noise[0] is None else {'noise': noise[0]}
+    z_enc_t, params_enc_t = reparameterizer(logits_map['encoder_logits'], **kw)
+    logits_map['prior_logits'] = clamp_variance(logits_map['prior_logits'], config, reparameterizer)
+    kw = {} if noise[1] is None else {'noise': noise[1]}
+    z_prior_t, params_prior_t = reparameterizer(logits_map['prior_logits'], **kw)
+    z = {'prior': z_prior_t, 'posterior': z_enc_t, 'x_features': logits_map['x_features']}
+    params = {'prior': params_prior_t, 'posterior': params_enc_t}
+    return z, params
+
+
+def kld(reparameterizer, dist, config):
+    """vrnn.py:723-733."""
+    prior_kl = reparameterizer.kl(dist['prior']) if config['use_prior_kl'] is True else 0
+    return reparameterizer.kl(dist['posterior'], dist['prior']) + prior_kl
+
+
+def loss_function_aggregate(step_losses):
+    """vrnn.py:767-803 (_add_loss_map + _mean_map) on already computed per-step dicts."""
+    agg = None
+    for lt in step_losses:
+        if agg is None:
+            agg = {**lt, 'count': 1}
+            continue
+        for k, v in lt.items():
+            agg[k] = agg[k] + v
+        agg['count'] += 1
+    for k in agg.keys():
+        if k != 'count':
+            agg[k] = agg[k] / agg['count']
+    return agg
+
+
+def loss_function(reparameterizer, config, recon_x, x, params, K=1, kl_beta=None, additive=False, inv_count=None):
+    """vrnn.py:805-829 (additive=True: additive_vrnn.py:78-104, every step scored on the LAST
+    reconstruction).  recon_x / params: per-step lists; x: per-step list or one tensor for all steps."""
+    assert len(recon_x) == len(params)
+    assert K == 1, "Monte carlo sampling for decoding not implemented for VRNN"
+    T = len(recon_x)
+    if not isinstance(x, list) and len(x) != len(recon_x):
+        x = [x for _ in range(T)]
+        if additive:
+            recon_x = [recon_x[-1] for _ in range(T)]
+    B = recon_x[0].shape[0]
+    klds = torch.cat([kld(reparameterizer, p, config) for p in params], 0)            # [T*B]
+    recon_all = torch.cat([r.reshape(B, -1) for r in recon_x], 0)                      # [T*B, D or 2D]
+    x_all = torch.cat([xi.reshape(B, -1) for xi in x], 0)
+    kl_beta = config['kl_beta'] if kl_beta is None else kl_beta
+    if inv_count is None:
+        inv_count = 1.0 / (T * B)
+    else:
+        inv_count = inv_count / T
+    _, loss, elbo, means = F_.nll_elbo(x_all, recon_all, config['nll_type'], kld=klds, kl_beta=kl_beta,
+                                       inv_count=inv_count)
+    out = _pack(loss.view(T, B).mean(0), elbo.view(T, B).mean(0), means, kl_beta, loss.dtype)
+    out['count'] = T
+    return out
