@@ -28,7 +28,7 @@ def _local_loss(nll, kld, beta, inv_count):
             'kl_beta_scalar': beta, 'mut_info_mean': z}
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, outdir):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -56,23 +56,23 @@ def _worker(rank, world, port, q):
     mean = (nlp.sum() / Bg).reshape(1)
     VD.all_reduce_inplace(mean)
     flow_kl = mean - logdet[sl, 0]
-    q.put((rank, row0, rows, {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()},
-           mu_mean.detach(), lv_mean.detach(), lg.grad.clone(), flow_kl))
+    # results go through a file: tensors put on an mp.Queue travel as fds that die with this process
+    torch.save((rank, row0, rows, {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()},
+                mu_mean.detach(), lv_mean.detach(), lg.grad.clone(), flow_kl), os.path.join(outdir, 'r%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_rank():
+def test_two_ranks_equal_one_rank(tmp_path):
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
-        p.join(60)
+        p.join(180)
         assert p.exitcode == 0
+    res = [torch.load(os.path.join(str(tmp_path), 'r%d.pt' % r), weights_only=True) for r in range(world)]
 
     torch.manual_seed(0)
     Bg, L, F = 37, 8, 6
