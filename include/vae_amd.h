@@ -16,8 +16,9 @@
  *     reductions are always fp32 inside the kernels;
  *   - rows are samples.  `row_stride` / `stride_*` are in ELEMENTS; tensors
  *     without a stride argument are contiguous;
- *   - `workspace` is scratch of at least vae_workspace_bytes() bytes that one call
- *     may use at a time (per stream);
+ *   - `workspace` is scratch of at least vae_workspace_bytes() bytes, ZEROED ONCE by the
+ *     caller when it is created (the kernels leave its counters at zero again), used by one
+ *     call at a time (per stream); the batch means are finished inside the producing kernel;
  *   - return value: VAE_OK, VAE_ERR_ARG (bad shape / null / dtype) or
  *     VAE_ERR_LAUNCH (hipGetLastError() != hipSuccess after the launches);
  *   - a call with B == 0 is a no-op that returns VAE_OK.

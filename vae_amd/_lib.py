@@ -116,7 +116,7 @@ def workspace(device):
     ws = _workspaces.get(key)
     if ws is None:
         nbytes = load().vae_workspace_bytes()
-        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)  # zeroed once: ticket counters
         _workspaces[key] = ws
     return ws
 

@@ -5,6 +5,6 @@
 
 extern "C" {
 int vae_abi_version(void) { return 1; }
-// one partial per block (<= kMaxGrid) x up to 8 scalars per kernel
-size_t vae_workspace_bytes(void) { return (size_t)vae::kMaxGrid * 8 * sizeof(float); }
+// counters + group partials + one partial per block x up to 8 scalars (common.hpp, grid_reduce)
+size_t vae_workspace_bytes(void) { return vae::kWorkspaceFloats * sizeof(float); }
 }

@@ -67,7 +67,7 @@ __device__ __forceinline__ float sigmoid_b(float v) { return 1.0f / (1.0f + expf
 template <typename T, int V, int U>
 __global__ __launch_bounds__(kBlock) void beta_split_fwd_kernel(
     const T* __restrict__ logits, int64_t row_stride, T* __restrict__ c1, T* __restrict__ c0, T* __restrict__ kl,
-    float* __restrict__ partials, int64_t B, int L, int G, int64_t tiles) {
+    float* __restrict__ ws, float mean_scale, float* __restrict__ means, int64_t B, int L, int G, int64_t tiles) {
   const int rpb = kBlock / G;
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void beta_split_fwd_kernel(
     klr = group_sum(klr, G);
     if (row < B && sub == 0) kl[row] = from_f32<T>(klr);
   }
-  block_partials<2>(acc, partials);
+  if (ws) grid_reduce<2>(acc, ws, mean_scale, means);
 }
 
 // glogits = sigmoid' * (g_conc + gkl * dKL/dconc + g_mean * mean_scale)
@@ -212,7 +212,6 @@ __global__ __launch_bounds__(kBlock) void beta_kl_kernel(
   }
 }
 
-void launch_finalize(const float* partials, int nblocks, int n, float scale, float* out, hipStream_t stream);
 
 template <typename T>
 static int beta_split_fwd_dispatch(const void* logits, int64_t rs, void* c1, void* c0, void* kl, float* means,
@@ -222,14 +221,13 @@ static int beta_split_fwd_dispatch(const void* logits, int64_t rs, void* c1, voi
   const RowGeom g = row_geom(B, vec ? L / VN : L, kGridReduce);
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((beta_split_fwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                         (const T*)logits, rs, (T*)c1, (T*)c0, (T*)kl, workspace, B, (int)L, g.G,
-                                         g.tiles));
+                                         (const T*)logits, rs, (T*)c1, (T*)c0, (T*)kl, means ? workspace : nullptr,
+                                         mean_scale, means, B, (int)L, g.G, g.tiles));
   } else {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((beta_split_fwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                         (const T*)logits, rs, (T*)c1, (T*)c0, (T*)kl, workspace, B, (int)L, g.G,
-                                         g.tiles));
+                                         (const T*)logits, rs, (T*)c1, (T*)c0, (T*)kl, means ? workspace : nullptr,
+                                         mean_scale, means, B, (int)L, g.G, g.tiles));
   }
-  if (means) launch_finalize(workspace, g.grid, 2, mean_scale, means, stream);
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 

@@ -200,24 +200,94 @@ __device__ __forceinline__ float row_max(float v, int G) {
   return s;
 }
 
-// Block-level sum of N per-thread accumulators -> partials[blockIdx.x * N + k].
-// Fixed order (lane butterfly, then waves 0..3), so results are reproducible.
+// ---------------------------------------------------------------------------------------------
+// Batch scalars (the *_mean entries): grid-wide sum of N <= 8 per-thread accumulators, finished
+// inside the producing kernel (no second launch), deterministic for a given grid.
+//   level 0: lane butterfly + LDS across the 4 waves -> bpart[block][k]
+//   level 1: blocks are grouped by 64; the LAST block of a group to arrive (ticket counter) sums
+//            the group's partials in block order -> gpart[group][k]
+//   level 2: the last group to finish sums the <= 256 group partials in group order (double),
+//            scales, writes out[k].
+// Which block arrives last varies from run to run; what it adds, and in which order, does not.
+// Hand-off = cdna_hip_programming.md Guideline 16, the all-sc1 form: every shared word (partials,
+// counters) is written with a relaxed agent-scope atomic store (write-through, no release fence --
+// a per-block agent release fence measured 7x slower end to end), the storing wave drains
+// (s_waitcnt vmcnt(0)) before ITS lane 0 takes a ticket with a relaxed agent-scope fetch_add, and
+// the closing wave reads every shared word with relaxed agent-scope atomic loads (sc1: bypass the
+// CU's L1, so no acquire fence).  Only wave 0 of a block takes part after the LDS step; no spinning.
+// Counters are back at 0 when the kernel ends, so the workspace only has to be zeroed once.
+// Workspace layout (floats): [0,512) counters (uint32; 0..255 groups, 256 final) | [512,2560)
+// gpart[256][8] | [2560, ...) bpart[kReduceGridMax][8].
+// ---------------------------------------------------------------------------------------------
+constexpr int kReduceGridMax = 16384;
+constexpr int kReduceGroup = 64;
+constexpr size_t kWorkspaceFloats = 512 + 256 * 8 + (size_t)kReduceGridMax * 8;
+
+__device__ __forceinline__ void shared_store(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float shared_load(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wave 0 only: drain this wave's stores, lane 0 draws a ticket; true in every lane if it was the last
+__device__ __forceinline__ bool drain_and_ticket(unsigned int* counter, unsigned int last_value) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned int t = 0;
+  if ((threadIdx.x & 63) == 0) t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  t = __builtin_amdgcn_readfirstlane(t);
+  asm volatile("" ::: "memory");
+  return t == last_value;
+}
+
 template <int N>
-__device__ __forceinline__ void block_partials(float (&acc)[N], float* __restrict__ partials) {
-  __shared__ float lds[kBlock / 64][N];
+__device__ __forceinline__ void grid_reduce(float (&acc)[N], float* __restrict__ ws, float scale,
+                                            float* __restrict__ out) {
+  static_assert(N <= 8, "at most 8 batch scalars per kernel");
+  __shared__ float lds[kBlock / 64][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned int* counters = reinterpret_cast<unsigned int*>(ws);
+  float* gpart = ws + 512;
+  float* bpart = ws + 512 + 256 * 8;
+  const int grid = gridDim.x;
+  const int group = blockIdx.x / kReduceGroup;
+  const int ngroups = (grid + kReduceGroup - 1) / kReduceGroup;
+  const int gsize = min(kReduceGroup, grid - group * kReduceGroup);
+
+  // level 0: block sums
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    float s = wave_sum(acc[k]);
+    const float s = wave_sum(acc[k]);
     if (lane == 0) lds[wave][k] = s;
   }
   __syncthreads();
-  if (threadIdx.x < N) {
+  if (wave != 0) return;
+  if (lane < N) {
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) s += lds[w][threadIdx.x];
-    partials[(size_t)blockIdx.x * N + threadIdx.x] = s;
+    for (int w = 0; w < kBlock / 64; ++w) s += lds[w][lane];
+    shared_store(&bpart[(size_t)blockIdx.x * 8 + lane], s);
   }
+  if (!drain_and_ticket(&counters[group], (unsigned int)(gsize - 1))) return;
+
+  // level 1: this block closes its group of <= 64 blocks
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    float v = lane < gsize ? shared_load(&bpart[((size_t)group * kReduceGroup + lane) * 8 + k]) : 0.f;
+    v = wave_sum(v);
+    if (lane == 0) shared_store(&gpart[group * 8 + k], v);
+  }
+  if (lane == 0) __hip_atomic_store(&counters[group], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!drain_and_ticket(&counters[256], (unsigned int)(ngroups - 1))) return;
+
+  // level 2: this block closes the grid
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double v = 0.0;
+    for (int g = lane; g < ngroups; g += 64) v += (double)shared_load(&gpart[g * 8 + k]);
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) out[k] = (float)(v * (double)scale);
+  }
+  if (lane == 0) __hip_atomic_store(&counters[256], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Philox4x32-10 counter RNG (Salmon et al. 2011), used when the caller passes no
@@ -310,10 +380,10 @@ struct RowGeom {
 // row has at least 64 vectors, else the smallest power of two that covers it.  Measured
 // (scripts/ab.py): for 784-pixel rows G = 64 beats G = 8/16 by 20-45 % on the store-heavy
 // backward although 23 % of the lane slots of the last pass idle.
-// Grid: kernels with a per-block epilogue (block partials of the batch means) run best with
-// 4 resident blocks per CU (cap 1024); pure streaming kernels get one tile per block.
+// Grid: one tile per block (measured: +8 % over a 2048-block grid-stride loop); kernels that
+// also reduce batch scalars are capped at kReduceGridMax blocks (the partials buffer).
 // VAE_AMD_G / VAE_AMD_U / VAE_AMD_MAXGRID override (tuning only).
-constexpr int kGridReduce = 1024;
+constexpr int kGridReduce = 1024;  // measured: the per-block ticket costs more than it saves beyond ~4 blocks/CU
 constexpr int64_t kGridStream = 1 << 20;
 
 inline RowGeom row_geom(int64_t rows, int64_t vecs_per_row, int64_t max_grid = kGridReduce) {
@@ -333,7 +403,7 @@ inline RowGeom row_geom(int64_t rows, int64_t vecs_per_row, int64_t max_grid = k
   }
   if (const char* e = getenv("VAE_AMD_MAXGRID")) {
     const int64_t v = atoll(e);
-    if (v >= 1) max_grid = (max_grid <= kMaxGrid && v > kMaxGrid) ? kMaxGrid : v;  // partials buffer bound
+    if (v >= 1) max_grid = (max_grid <= kReduceGridMax && v > kReduceGridMax) ? kReduceGridMax : v;
   }
   g.rows_per_block = kBlock / G;
   g.tiles = (rows + g.rows_per_block - 1) / g.rows_per_block;

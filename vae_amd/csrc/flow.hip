@@ -19,8 +19,9 @@ constexpr float kHalfLog2PiF = 0.91893853320467274178f;
 // rowval[row] = scale * sum_f 0.5 u^2 + cadd ; optional block partial sums of rowval
 template <typename T, int V, int U>
 __global__ __launch_bounds__(kBlock) void flow_rows_kernel(const T* __restrict__ u, T* __restrict__ rowval,
-                                                          float* __restrict__ partials, int64_t B, int F,
-                                                          float scale, float cadd, int G, int64_t tiles) {
+                                                          float* __restrict__ ws, float inv_count,
+                                                          float* __restrict__ mean_out, int64_t B, int F, float scale,
+                                                          float cadd, int G, int64_t tiles) {
   const int rpb = kBlock / G;
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(kBlock) void flow_rows_kernel(const T* __restrict__
       acc[0] += v;
     }
   }
-  if (partials) block_partials<1>(acc, partials);
+  if (ws) grid_reduce<1>(acc, ws, inv_count, mean_out);
 }
 
 // 2-D: kl[i] = mean[0] - logdet[i].   3-D: kl[i] = rowval[i] - (1/R) sum_r logdet[i, r]
@@ -94,7 +95,6 @@ __global__ __launch_bounds__(kBlock) void flow_bwd_kernel(const T* __restrict__ 
   }
 }
 
-void launch_finalize(const float* partials, int nblocks, int n, float scale, float* out, hipStream_t stream);
 
 template <typename T>
 static int flow_fwd_dispatch(const void* u, const void* logdet, int64_t R, void* kl, float* mean_io,
@@ -110,16 +110,17 @@ static int flow_fwd_dispatch(const void* u, const void* logdet, int64_t R, void*
     float* partials = cross_batch ? workspace : nullptr;
     if (vec) {
       VAE_SWITCH_U(g.U, hipLaunchKernelGGL((flow_rows_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                           (const T*)u, (T*)kl, partials, B, (int)row_len, scale, cadd, g.G, g.tiles));
+                                           (const T*)u, (T*)kl, partials, inv_count, mean_io, B, (int)row_len, scale, cadd, g.G,
+                                           g.tiles));
     } else {
       VAE_SWITCH_U(g.U, hipLaunchKernelGGL((flow_rows_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                           (const T*)u, (T*)kl, partials, B, (int)row_len, scale, cadd, g.G, g.tiles));
+                                           (const T*)u, (T*)kl, partials, inv_count, mean_io, B, (int)row_len, scale, cadd, g.G,
+                                           g.tiles));
     }
-    if (cross_batch) launch_finalize(workspace, g.grid, 1, inv_count, mean_io, stream);
   }
   if (phase != 1) {
     int64_t blocks = (B + kBlock - 1) / kBlock;
-    const int grid = (int)(blocks < kMaxGrid ? blocks : kMaxGrid);
+    const int grid = (int)(blocks < kReduceGridMax ? blocks : kReduceGridMax);
     hipLaunchKernelGGL((flow_combine_kernel<T>), dim3(grid), dim3(kBlock), 0, stream, (const T*)logdet, mean_io,
                        (T*)kl, B, (int)R, cross_batch);
   }

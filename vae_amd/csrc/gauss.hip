@@ -22,8 +22,8 @@ namespace vae {
 template <typename T, int V, int U>
 __global__ __launch_bounds__(kBlock) void gauss_fwd_kernel(
     const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ noise, T* __restrict__ z,
-    T* __restrict__ s_out, T* __restrict__ kl, float* __restrict__ partials, int64_t B, int L, float eps_tol,
-    int training, uint64_t seed, uint64_t offset, int64_t row0, int G, int64_t tiles) {
+    T* __restrict__ s_out, T* __restrict__ kl, float* __restrict__ ws, float mean_scale,
+    float* __restrict__ means, int64_t B, int L, float eps_tol, int training, uint64_t seed, uint64_t offset, int64_t row0, int G, int64_t tiles) {
   const int rpb = kBlock / G;
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void gauss_fwd_kernel(
     klr = group_sum(klr, G);
     if (row < B && sub == 0) kl[row] = from_f32<T>(klr);
   }
-  block_partials<2>(acc, partials);
+  if (ws) grid_reduce<2>(acc, ws, mean_scale, means);
 }
 
 // ---------------------------------------------------------------------------
@@ -224,32 +224,6 @@ __global__ __launch_bounds__(kBlock) void gauss_kl_bwd_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------
-// finalize: out[k] = scale * sum_b partials[b*n + k], n <= 8.  One block, one pass:
-// thread t sums value k = t & 7 over blocks (t >> 3), (t >> 3) + 32, ... in double, then
-// thread k adds the 32 strided sums in a fixed order (deterministic, no atomics).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void finalize_kernel(const float* __restrict__ partials, int nblocks, int n,
-                                                         float scale, float* __restrict__ out) {
-  __shared__ double lds[kBlock / 8][8];
-  const int k = threadIdx.x & 7, set = threadIdx.x >> 3;
-  double s = 0.0;
-  if (k < n)
-    for (int b = set; b < nblocks; b += kBlock / 8) s += (double)partials[(size_t)b * n + k];
-  lds[set][k] = s;
-  __syncthreads();
-  if (threadIdx.x < n) {
-    double tot = 0.0;
-#pragma unroll
-    for (int w = 0; w < kBlock / 8; ++w) tot += lds[w][threadIdx.x];
-    out[threadIdx.x] = (float)(tot * (double)scale);
-  }
-}
-
-void launch_finalize(const float* partials, int nblocks, int n, float scale, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, stream, partials, nblocks, n, scale, out);
-}
-
 template <typename T>
 static int gauss_fwd_dispatch(const void* logits, int64_t row_stride, const void* noise, void* z, void* s_out,
                               void* kl, float* means, float* workspace, int64_t B, int64_t L, float eps_tol,
@@ -258,17 +232,19 @@ static int gauss_fwd_dispatch(const void* logits, int64_t row_stride, const void
   constexpr int VN = VecOf<T>::n;
   const bool vec = (L % VN == 0) && (row_stride % VN == 0) && aligned16(logits) && (!z || aligned16(z)) &&
                    (!noise || aligned16(noise)) && (!s_out || aligned16(s_out));
-  const RowGeom g = row_geom(B, vec ? L / VN : L);
+  const RowGeom g = row_geom(B, vec ? L / VN : L, means ? kGridReduce : kGridStream);
+  if (!means) workspace = nullptr;
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gauss_fwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
                                          (const T*)logits, row_stride, (const T*)noise, (T*)z, (T*)s_out, (T*)kl,
-                                         workspace, B, (int)L, eps_tol, training, seed, offset, row0, g.G, g.tiles));
+                                         workspace, mean_scale, means, B, (int)L, eps_tol, training, seed, offset,
+                                         row0, g.G, g.tiles));
   } else {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gauss_fwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, stream,
                                          (const T*)logits, row_stride, (const T*)noise, (T*)z, (T*)s_out, (T*)kl,
-                                         workspace, B, (int)L, eps_tol, training, seed, offset, row0, g.G, g.tiles));
+                                         workspace, mean_scale, means, B, (int)L, eps_tol, training, seed, offset,
+                                         row0, g.G, g.tiles));
   }
-  if (means) launch_finalize(workspace, g.grid, 2, mean_scale, means, stream);
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 
