@@ -17,15 +17,19 @@ knobs = {k: opts.get(k, 'auto').split(',') for k in ('G', 'U', 'MAXGRID')}
 only = opts.get('kernels', '').split(',') if opts.get('kernels') else None
 B, L, D = int(opts.get('B', 65536)), int(opts.get('L', 512)), int(opts.get('D', 784))
 dev = torch.device('cuda', 0)
-f32 = dict(dtype=torch.float32, device=dev)
-logits = torch.randn(B, 2 * L, **f32); noise = torch.randn(B, L, **f32)
-x = (torch.rand(B, D, **f32) < 0.13).float(); recon = torch.randn(B, D, **f32)
-gz = torch.randn(B, L, **f32)
+DT = torch.bfloat16 if opts.get('dtype') == 'bf16' else torch.float32
+DC = 1 if DT == torch.bfloat16 else 0
+ES = 2 if DC else 4
+f32 = dict(dtype=DT, device=dev)
+R = lambda *sh: torch.randn(*sh, device=dev).to(DT)
+logits = R(B, 2 * L); noise = R(B, L)
+x = (torch.rand(B, D, device=dev) < 0.13).to(DT); recon = R(B, D)
+gz = R(B, L)
 z = torch.empty(B, L, **f32); logvar = torch.empty(B, L, **f32); kl = torch.empty(B, **f32)
 nll = torch.empty(B, **f32); loss = torch.empty(B, **f32); elbo = torch.empty(B, **f32)
-scal = torch.zeros(8, **f32); gmeans = torch.zeros(6, **f32); gmeans[0] = 1
+scal = torch.zeros(8, device=dev); gmeans = torch.zeros(6, device=dev); gmeans[0] = 1
 grecon = torch.empty(B, D, **f32); gkld = torch.empty(B, **f32); glogits = torch.empty(B, 2 * L, **f32)
-ws = torch.zeros(1 << 18, **f32)
+ws = torch.zeros(1 << 18, device=dev)
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 
@@ -40,12 +44,12 @@ for path in libs:
 
 def kernels(lib):
     return {
-        'gauss_fwd': (lambda: lib.vae_gauss_reparam_kl_fwd(p(logits), 2 * L, p(noise), p(z), p(logvar), p(kl), p(scal), p(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st), (16 * L + 4) * B),
-        'gauss_fwd_nomeans': (lambda: lib.vae_gauss_reparam_kl_fwd(p(logits), 2 * L, p(noise), p(z), p(logvar), p(kl), None, p(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st), (16 * L + 4) * B),
-        'gauss_fwd_nologvar': (lambda: lib.vae_gauss_reparam_kl_fwd(p(logits), 2 * L, p(noise), p(z), None, p(kl), p(scal), p(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st), (16 * L + 4) * B),
-        'gauss_bwd': (lambda: lib.vae_gauss_reparam_kl_bwd(p(logits), 2 * L, p(noise), p(gz), None, p(gkld), None, p(glogits), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st), (24 * L + 4) * B),
-        'nll_fwd': (lambda: lib.vae_nll_elbo_fwd(p(x), p(recon), 0, p(kl), None, None, 1.0, 1.0 / B, p(nll), p(loss), p(elbo), p(scal), p(ws), B, D, 0, st), (8 * D + 12) * B),
-        'nll_bwd': (lambda: lib.vae_nll_elbo_bwd(p(x), p(recon), 0, None, None, None, p(gmeans), 1.0, 1.0 / B, p(grecon), p(gkld), None, None, B, D, 0, st), 12 * D * B),
+        'gauss_fwd': (lambda: lib.vae_gauss_reparam_kl_fwd(p(logits), 2 * L, p(noise), p(z), p(logvar), p(kl), p(scal), p(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, DC, st), (4 * L * ES + ES) * B),
+        'gauss_fwd_nomeans': (lambda: lib.vae_gauss_reparam_kl_fwd(p(logits), 2 * L, p(noise), p(z), p(logvar), p(kl), None, p(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, DC, st), (4 * L * ES + ES) * B),
+        'gauss_fwd_nologvar': (lambda: lib.vae_gauss_reparam_kl_fwd(p(logits), 2 * L, p(noise), p(z), None, p(kl), p(scal), p(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, DC, st), (4 * L * ES + ES) * B),
+        'gauss_bwd': (lambda: lib.vae_gauss_reparam_kl_bwd(p(logits), 2 * L, p(noise), p(gz), None, p(gkld), None, p(glogits), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, DC, st), (6 * L * ES + ES) * B),
+        'nll_fwd': (lambda: lib.vae_nll_elbo_fwd(p(x), p(recon), 0, p(kl), None, None, 1.0, 1.0 / B, p(nll), p(loss), p(elbo), p(scal), p(ws), B, D, DC, st), (2 * D + 3) * ES * B),
+        'nll_bwd': (lambda: lib.vae_nll_elbo_bwd(p(x), p(recon), 0, None, None, None, p(gmeans), 1.0, 1.0 / B, p(grecon), p(gkld), None, None, B, D, DC, st), 3 * D * ES * B),
     }
 
 

@@ -1,0 +1,170 @@
+"""Per-kernel roofline table for the BASELINE.json configs other than the bench.py headline (GPU box).
+
+    python scripts/bench_configs.py [--json out.json]
+
+Every kernel is called through the C ABI on preallocated buffers; time = HIP events around 20
+back-to-back launches after 5 warm-ups; bytes = algorithmic bytes of that launch.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vae_amd import _lib
+from vae_amd._lib import call, ptr
+
+dev = torch.device('cuda', 0)
+ws = _lib.workspace(dev)
+st = _lib.stream_ptr(dev)
+rows = []
+
+
+def T(*shape, dtype=torch.float32, kind='randn'):
+    if kind == 'randn':
+        return torch.randn(*shape, device=dev, dtype=torch.float32).to(dtype)
+    if kind == 'rand':
+        return torch.rand(*shape, device=dev, dtype=torch.float32).to(dtype)
+    return torch.empty(*shape, device=dev, dtype=dtype)
+
+
+def timeit(name, cfg, fn, nbytes, iters=20):
+    for _ in range(5):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    gbs = nbytes / ms / 1e6
+    rows.append({'kernel': name, 'config': cfg, 'ms': round(ms, 5), 'algorithmic_MB': round(nbytes / 1e6, 1),
+                 'GBs': round(gbs), 'frac_of_8TBs': round(gbs / 8000, 3)})
+    print('%-26s %-44s %9.4f ms %8.1f MB %6.0f GB/s  %5.1f%%' % (name, cfg, ms, nbytes / 1e6, gbs, gbs / 80), flush=True)
+
+
+def gauss(B, L, dtype=torch.float32, philox=False):
+    es = 2 if dtype == torch.bfloat16 else 4
+    dc = 1 if dtype == torch.bfloat16 else 0
+    logits, noise, gz = T(B, 2 * L, dtype=dtype), T(B, L, dtype=dtype), T(B, L, dtype=dtype)
+    z, lv, kl, gkl = T(B, L, dtype=dtype, kind='e'), T(B, L, dtype=dtype, kind='e'), T(B, dtype=dtype, kind='e'), T(B, dtype=dtype)
+    gl, means = T(B, 2 * L, dtype=dtype, kind='e'), torch.zeros(2, device=dev)
+    n = None if philox else noise
+    cfg = 'B=%d L=%d %s%s' % (B, L, 'bf16' if dc else 'f32', ' philox' if philox else '')
+    timeit('gauss_reparam_kl_fwd', cfg, lambda: call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, ptr(n), ptr(z), ptr(lv), ptr(kl), ptr(means), ptr(ws), B, L, 1e-6, 1.0 / (B * L), 1, 1, 1, 0, dc, st),
+           B * ((4 if philox else 5) * L * es + es) - B * L * es)  # SURVEY figure: logits + noise + z + kl (logvar write not counted)
+    timeit('gauss_reparam_kl_bwd', cfg, lambda: call('vae_gauss_reparam_kl_bwd', ptr(logits), 2 * L, ptr(n), ptr(gz), None, ptr(gkl), None, ptr(gl), B, L, 1e-6, 1.0 / (B * L), 1, 1, 1, 0, dc, st),
+           B * ((5 if philox else 6) * L * es + es))
+
+
+def gauss_pair(B, L):
+    mq, sq, mp, sp = T(B, L), T(B, L), T(B, L), T(B, L, kind='rand') + 0.1
+    kl, gkl = T(B, kind='e'), T(B)
+    g = [T(B, L, kind='e') for _ in range(4)]
+    cfg = 'B=%d L=%d f32 (VRNN post||prior)' % (B, L)
+    timeit('gauss_kl_fwd', cfg, lambda: call('vae_gauss_kl_fwd', ptr(mq), L, ptr(sq), L, ptr(mp), L, ptr(sp), L, ptr(kl), B, L, 0, st), B * (16 * L + 4))
+    timeit('gauss_kl_bwd', cfg, lambda: call('vae_gauss_kl_bwd', ptr(mq), L, ptr(sq), L, ptr(mp), L, ptr(sp), L, ptr(gkl), ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(g[3]), B, L, 0, st), B * (32 * L + 4))
+
+
+def gumbel(B, K, philox=False):
+    logits, U = T(B, K), T(B, K, kind='rand')
+    y, zh, lq, gy, gl = [T(B, K, kind='e') for _ in range(5)]
+    gy.normal_()
+    u = None if philox else U
+    cfg = 'B=%d K=%d f32%s' % (B, K, ' philox' if philox else '')
+    timeit('gumbel_fwd', cfg, lambda: call('vae_gumbel_fwd', ptr(logits), K, ptr(u), ptr(y), ptr(zh), ptr(lq), B, K, 0.7, 1, 1, 0, 0, st), B * ((16 if philox else 20) * K))
+    timeit('gumbel_bwd (gy only)', cfg, lambda: call('vae_gumbel_bwd', ptr(y), ptr(lq), ptr(gy), None, None, ptr(gl), B, K, 0.7, 0, st), B * 12 * K)
+    kl, gkl = T(B, kind='e'), T(B)
+    timeit('categorical_kl_fwd', cfg, lambda: call('vae_categorical_kl_fwd', ptr(lq), K, ptr(logits), K, ptr(kl), B, K, 0, st), B * (8 * K + 4))
+    timeit('categorical_kl_bwd', cfg, lambda: call('vae_categorical_kl_bwd', ptr(lq), K, ptr(logits), K, ptr(gkl), ptr(y), ptr(zh), B, K, 0, st), B * (16 * K + 4))
+
+
+def concat(B, L, K):
+    W = 2 * L + K
+    logits, noise, U = T(B, W), T(B, L), T(B, K, kind='rand')
+    z, lv, kl, means = T(B, L, kind='e'), T(B, L, kind='e'), T(B, kind='e'), torch.zeros(2, device=dev)
+    y, zh, lq = [T(B, K, kind='e') for _ in range(3)]
+    disc = ctypes.c_void_p(logits.data_ptr() + 2 * L * 4)
+
+    def fn():
+        call('vae_gauss_reparam_kl_fwd', ptr(logits), W, ptr(noise), ptr(z), ptr(lv), ptr(kl), ptr(means), ptr(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st)
+        call('vae_gumbel_fwd', disc, W, ptr(U), ptr(y), ptr(zh), ptr(lq), B, K, 1.0, 0, 0, 0, 0, st)
+    timeit('concat fwd (gauss+gumbel)', 'B=%d L=%d K=%d f32, strided views of one logits buffer' % (B, L, K), fn, B * (16 * L + 4 + 20 * K))
+
+
+def bernoulli(B, K):
+    logits, U, gy = T(B, K), T(B, K, kind='rand'), T(B, K)
+    y, zh, gl, kl, gkl = T(B, K, kind='e'), T(B, K, kind='e'), T(B, K, kind='e'), T(B, kind='e'), T(B)
+    cfg = 'B=%d K=%d f32' % (B, K)
+    timeit('bernoulli_fwd', cfg, lambda: call('vae_bernoulli_fwd', ptr(logits), K, ptr(U), ptr(y), ptr(zh), B, K, 0.7, 0, 0, 0, 0, st), B * 16 * K)
+    timeit('bernoulli_bwd', cfg, lambda: call('vae_bernoulli_bwd', ptr(logits), K, ptr(y), ptr(gy), None, ptr(gl), B, K, 0.7, 0, st), B * 16 * K)
+    timeit('bernoulli_kl_fwd', cfg, lambda: call('vae_bernoulli_kl_fwd', ptr(logits), K, None, 0, ptr(kl), B, K, 0, st), B * (4 * K + 4))
+    timeit('bernoulli_kl_bwd', cfg, lambda: call('vae_bernoulli_kl_bwd', ptr(logits), K, None, 0, ptr(gkl), ptr(gl), None, B, K, 0, st), B * (8 * K + 4))
+
+
+def beta(B, L):
+    logits = T(B, 2 * L)
+    c1, c0, kl, gkl, gl = T(B, L, kind='e'), T(B, L, kind='e'), T(B, kind='e'), T(B), T(B, 2 * L, kind='e')
+    g1 = T(B, L)
+    means = torch.zeros(2, device=dev)
+    cfg = 'B=%d L=%d f32' % (B, L)
+    timeit('beta_split_kl_fwd', cfg, lambda: call('vae_beta_split_kl_fwd', ptr(logits), 2 * L, ptr(c1), ptr(c0), ptr(kl), ptr(means), ptr(ws), B, L, 1.0 / (B * L), 0, st), B * (16 * L + 4))
+    timeit('beta_split_kl_bwd', cfg, lambda: call('vae_beta_split_kl_bwd', ptr(logits), 2 * L, ptr(g1), ptr(g1), ptr(gkl), None, ptr(gl), B, L, 1.0 / (B * L), 0, st), B * (24 * L + 4))
+
+
+def flow(B, F):
+    u, ld, kl, gu = T(B, F), T(B, 1), T(B, kind='e'), T(B, F, kind='e')
+    mean, gsum = torch.zeros(1, device=dev), torch.ones(1, device=dev)
+    cfg = 'B=%d F=%d f32 cross-batch' % (B, F)
+    timeit('flow_kl_fwd', cfg, lambda: call('vae_flow_kl_fwd', ptr(u), ptr(ld), 1, ptr(kl), ptr(mean), ptr(ws), B, F, 1.0 / B, 1, 0, 0, st), B * (4 * F + 8))
+    timeit('flow_kl_bwd', cfg, lambda: call('vae_flow_kl_bwd', ptr(u), None, ptr(gsum), ptr(gu), B, F, 1.0 / B, 0, st), B * 8 * F)
+
+
+def nll(B, D, code, name, dtype=torch.float32):
+    es = 2 if dtype == torch.bfloat16 else 4
+    dc = 1 if dtype == torch.bfloat16 else 0
+    R = D if code == 0 else 2 * D
+    x = (T(B, D, kind='rand') * 255).floor().div(255).to(dtype) if code else (T(B, D, kind='rand') < 0.13).to(dtype)
+    recon, kld = T(B, R, dtype=dtype), T(B, dtype=dtype, kind='rand')
+    n, lo, el, gr, gk = T(B, dtype=dtype, kind='e'), T(B, dtype=dtype, kind='e'), T(B, dtype=dtype, kind='e'), T(B, R, dtype=dtype, kind='e'), T(B, dtype=dtype, kind='e')
+    means, gm = torch.zeros(6, device=dev), torch.zeros(6, device=dev)
+    gm[0] = 1
+    cfg = 'B=%d D=%d %s %s' % (B, D, name, 'bf16' if dc else 'f32')
+    timeit('nll_elbo_fwd', cfg, lambda: call('vae_nll_elbo_fwd', ptr(x), ptr(recon), code, ptr(kld), None, None, 1.0, 1.0 / B, ptr(n), ptr(lo), ptr(el), ptr(means), ptr(ws), B, D, dc, st), B * ((D + R) * es + 3 * es))
+    timeit('nll_elbo_bwd', cfg, lambda: call('vae_nll_elbo_bwd', ptr(x), ptr(recon), code, None, None, None, ptr(gm), 1.0, 1.0 / B, ptr(gr), ptr(gk), None, None, B, D, dc, st), B * (D + 2 * R) * es)
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--json', default=None)
+    args = ap.parse_args()
+    print('== C2 family: IsotropicGaussian + Bernoulli NLL sweeps')
+    for B, L in [(4096, 32), (16384, 128), (65536, 512), (65536, 1024)]:
+        gauss(B, L)
+    gauss(65536, 512, philox=True)
+    gauss(65536, 512, dtype=torch.bfloat16)
+    for B in (4096, 16384, 65536):
+        nll(B, 784, 0, 'bernoulli')
+    nll(65536, 784, 0, 'bernoulli', dtype=torch.bfloat16)
+    print('== C3: Gumbel-softmax / Concat')
+    for K in (32, 256, 1024):
+        gumbel(65536, K)
+    gumbel(65536, 256, philox=True)
+    concat(65536, 128, 256)
+    print('== C4: Gaussian->Flow, 3x64x64 discretized logistic')
+    nll(8192, 12288, 2, 'disc_logistic')
+    nll(8192, 12288, 1, 'gaussian')
+    flow(65536, 512)
+    print('== C5: VRNN per-step pair (B per step) and the time-batched loss (T*B rows)')
+    gauss(16384, 128)
+    gauss_pair(16384, 128)
+    nll(64 * 1024, 784, 0, 'bernoulli T=64 x B=1024')
+    print('== Bernoulli / Beta reparameterizers')
+    bernoulli(65536, 1024)
+    beta(65536, 512)
+    if args.json:
+        json.dump(rows, open(args.json, 'w'), indent=1)

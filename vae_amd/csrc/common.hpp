@@ -160,6 +160,14 @@ __device__ __forceinline__ float log1p_unit(float e) {
   return e < 1e-3f ? e * (1.0f - e * (0.5f - e * (1.0f / 3.0f))) : __logf(1.0f + e);
 }
 
+// log(1 + e) for any e >= 0 with full RELATIVE precision (Kahan: log(u) * e / (u - 1), u = fl(1 + e));
+// plain log(1 + e) loses eps/e of it, which a Normal scale softplus(v) + 1e-6 then squares.
+__device__ __forceinline__ float log1p_unit_any(float e) {
+  const float u = 1.0f + e;
+  const float d = u - 1.0f;
+  return d == 0.0f ? e : __logf(u) * (e * fast_rcp(d));
+}
+
 // Sum / max over the G lanes that share a row (G power of two, <= 64).  After the
 // butterfly every lane of the group holds the result.
 __device__ __forceinline__ float group_sum(float v, int G) {
@@ -203,40 +211,32 @@ __device__ __forceinline__ float row_max(float v, int G) {
 // ---------------------------------------------------------------------------------------------
 // Batch scalars (the *_mean entries): grid-wide sum of N <= 8 per-thread accumulators, finished
 // inside the producing kernel (no second launch), deterministic for a given grid.
-//   level 0: lane butterfly + LDS across the 4 waves -> bpart[block][k]
-//   level 1: blocks are grouped by 64; the LAST block of a group to arrive (ticket counter) sums
-//            the group's partials in block order -> gpart[group][k]
-//   level 2: the last group to finish sums the <= 256 group partials in group order (double),
-//            scales, writes out[k].
+//   step 0: lane butterfly + LDS across the 4 waves -> bpart[block][k]
+//   step 1: the LAST block to arrive (one ticket counter) sums the <= kGridReduce block partials
+//           in block order (double), scales, writes out[k].
 // Which block arrives last varies from run to run; what it adds, and in which order, does not.
 // Hand-off = cdna_hip_programming.md Guideline 16, the all-sc1 form: every shared word (partials,
-// counters) is written with a relaxed agent-scope atomic store (write-through, no release fence --
+// counter) is written with a relaxed agent-scope atomic store (write-through, no release fence --
 // a per-block agent release fence measured 7x slower end to end), the storing wave drains
 // (s_waitcnt vmcnt(0)) before ITS lane 0 takes a ticket with a relaxed agent-scope fetch_add, and
-// the closing wave reads every shared word with relaxed agent-scope atomic loads (sc1: bypass the
-// CU's L1, so no acquire fence).  Only wave 0 of a block takes part after the LDS step; no spinning.
-// Counters are back at 0 when the kernel ends, so the workspace only has to be zeroed once.
-// Workspace layout (floats): [0,512) counters (uint32; 0..255 groups, 256 final) | [512,2560)
-// gpart[256][8] | [2560, ...) bpart[kReduceGridMax][8].
+// the closing wave -- one per launch -- does one agent-scope acquire and then plain loads.
+// Only wave 0 of a block takes part after the LDS step; no spinning.
+// The counter is back at 0 when the kernel ends, so the workspace only has to be zeroed once.
+// Tickets: one counter for every block costs ~13 ns per block (same-address atomics serialise:
+// 13 us tail at 1024 blocks, measured), so blocks draw from kTicketFan sub-counters on separate
+// 64-byte lines and only the last block of each sub-counter draws from the master counter.
+// Workspace layout (floats): [0,16) master counter | [16*(1+s), ...) sub-counter s (one per 64 B)
+// | [1024, 1024 + kReduceGridMax*8) bpart.
 // ---------------------------------------------------------------------------------------------
-constexpr int kReduceGridMax = 16384;
-constexpr int kReduceGroup = 64;
-constexpr size_t kWorkspaceFloats = 512 + 256 * 8 + (size_t)kReduceGridMax * 8;
+constexpr int kReduceGridMax = 2048;
+constexpr int kTicketFan = 32;
+constexpr size_t kWorkspaceFloats = 1024 + (size_t)kReduceGridMax * 8;
 
 __device__ __forceinline__ void shared_store(float* p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float shared_load(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// wave 0 only: drain this wave's stores, lane 0 draws a ticket; true in every lane if it was the last
-__device__ __forceinline__ bool drain_and_ticket(unsigned int* counter, unsigned int last_value) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  unsigned int t = 0;
-  if ((threadIdx.x & 63) == 0) t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  t = __builtin_amdgcn_readfirstlane(t);
-  asm volatile("" ::: "memory");
-  return t == last_value;
 }
 
 template <int N>
@@ -245,15 +245,10 @@ __device__ __forceinline__ void grid_reduce(float (&acc)[N], float* __restrict__
   static_assert(N <= 8, "at most 8 batch scalars per kernel");
   __shared__ float lds[kBlock / 64][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned int* counters = reinterpret_cast<unsigned int*>(ws);
-  float* gpart = ws + 512;
-  float* bpart = ws + 512 + 256 * 8;
+  unsigned int* master = reinterpret_cast<unsigned int*>(ws);
+  float* bpart = ws + 1024;
   const int grid = gridDim.x;
-  const int group = blockIdx.x / kReduceGroup;
-  const int ngroups = (grid + kReduceGroup - 1) / kReduceGroup;
-  const int gsize = min(kReduceGroup, grid - group * kReduceGroup);
 
-  // level 0: block sums
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const float s = wave_sum(acc[k]);
@@ -265,29 +260,62 @@ __device__ __forceinline__ void grid_reduce(float (&acc)[N], float* __restrict__
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < kBlock / 64; ++w) s += lds[w][lane];
-    shared_store(&bpart[(size_t)blockIdx.x * 8 + lane], s);
+    if (grid == 1) {
+      out[lane] = s * scale;
+    } else {
+      shared_store(&bpart[(size_t)blockIdx.x * 8 + lane], s);
+    }
   }
-  if (!drain_and_ticket(&counters[group], (unsigned int)(gsize - 1))) return;
+  if (grid == 1) return;
+  // drain this wave's partial stores, then lane 0 draws a ticket from its sub-counter; the last
+  // block of a sub-counter draws from the master; the last there closes the grid
+  const int fan = grid < kTicketFan ? grid : kTicketFan;
+  const int sub = blockIdx.x % fan;
+  const unsigned int sub_count = (unsigned int)(grid / fan + (sub < grid % fan ? 1 : 0));
+  unsigned int* subc = master + 16 * (1 + sub);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned int t = 0;
+  if (lane == 0) {
+    t = __hip_atomic_fetch_add(subc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == sub_count - 1) {
+      __hip_atomic_store(subc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t = __hip_atomic_fetch_add(master, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t = (t == (unsigned int)(fan - 1)) ? 1u : 0u;
+    } else {
+      t = 0u;
+    }
+  }
+  t = __builtin_amdgcn_readfirstlane(t);
+  asm volatile("" ::: "memory");
+  if (!t) return;
+  unsigned int* counter = master;
 
-  // level 1: this block closes its group of <= 64 blocks
+  // this block closes the grid: ONE agent-scope acquire (drops this CU's stale lines; executed by
+  // this single block only), then plain 16-byte loads that the compiler can batch -- per-word sc1
+  // loads here cost ~1 us each in sequence (16 us tail at 1024 blocks, measured).
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4* bp4 = reinterpret_cast<const f4*>(bpart);
+  double v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = 0.0;
+  // lane j adds blocks j, j+64, ... in order; then a fixed butterfly over lanes
+#pragma unroll 4
+  for (int b = lane; b < grid; b += 64) {
+    const f4 lo = bp4[(size_t)b * 2];
+    f4 hi = {0.f, 0.f, 0.f, 0.f};
+    if (N > 4) hi = bp4[(size_t)b * 2 + 1];
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += (double)(k < 4 ? lo[k] : hi[k - 4]);
+  }
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    float v = lane < gsize ? shared_load(&bpart[((size_t)group * kReduceGroup + lane) * 8 + k]) : 0.f;
-    v = wave_sum(v);
-    if (lane == 0) shared_store(&gpart[group * 8 + k], v);
+    double x = v[k];
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    if (lane == 0) out[k] = (float)(x * (double)scale);
   }
-  if (lane == 0) __hip_atomic_store(&counters[group], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (!drain_and_ticket(&counters[256], (unsigned int)(ngroups - 1))) return;
-
-  // level 2: this block closes the grid
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    double v = 0.0;
-    for (int g = lane; g < ngroups; g += 64) v += (double)shared_load(&gpart[g * 8 + k]);
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (lane == 0) out[k] = (float)(v * (double)scale);
-  }
-  if (lane == 0) __hip_atomic_store(&counters[256], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Philox4x32-10 counter RNG (Salmon et al. 2011), used when the caller passes no
@@ -377,7 +405,8 @@ struct RowGeom {
 };
 
 // Lanes per row: a whole wave (G = 64: 1 KiB contiguous per load/store instruction) once the
-// row has at least 64 vectors, else the smallest power of two that covers it.  Measured
+// row has more than 64 vectors, else the smallest power of two that leaves every lane two
+// vectors per tensor (bf16 L=512, 64 vectors: G = 32 runs 40 % faster than G = 64).  Measured
 // (scripts/ab.py): for 784-pixel rows G = 64 beats G = 8/16 by 20-45 % on the store-heavy
 // backward although 23 % of the lane slots of the last pass idle.
 // Grid: one tile per block (measured: +8 % over a 2048-block grid-stride loop); kernels that
@@ -389,7 +418,7 @@ constexpr int64_t kGridStream = 1 << 20;
 inline RowGeom row_geom(int64_t rows, int64_t vecs_per_row, int64_t max_grid = kGridReduce) {
   RowGeom g;
   int G = 1;
-  while (G < 64 && G < vecs_per_row) G <<= 1;
+  while (G < 64 && (int64_t)G * 2 < vecs_per_row) G <<= 1;  // >= 2 vectors per lane and tensor in flight
   if (const char* e = getenv("VAE_AMD_G")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) G = v;
