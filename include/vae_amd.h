@@ -84,6 +84,29 @@ int vae_gauss_kl_bwd(const void* mu_q, int64_t stride_mu_q, const void* s_q, int
                      int64_t stride_mu_p, const void* s_p, int64_t stride_s_p, const void* gkl, void* g_mu_q,
                      void* g_s_q, void* g_mu_p, void* g_s_p, int64_t B, int64_t L, int dtype, vae_stream_t stream);
 
+/* ---- VRNN per-step pair ---------------------------------------------------------
+ * vrnn.py:419-447 (reparameterize: posterior draw, _clamp_variance :395-408 on the prior
+ * logits, prior draw) + vrnn.py:723-733 (kld: KL(post || prior) [+ KL(prior || N(0,1))]),
+ * one launch instead of ~5 per time step.
+ *   enc_logits, prior_logits [B, 2L] (strided); noise_* [B, L] or NULL (Philox; the prior
+ *   uses stream id offset ^ 2^63); z_* [B, L] (NULL allowed when !training);
+ *   logvar_post = enc[:, L:] + eps; clamped_prior_logits [B, 2L] = [mu_p | sigmoid(raw)];
+ *   logvar_prior = sigmoid(raw) + eps; kl_pair [B]; kl_prior [B] or NULL;
+ *   means: 4 floats (mu_q, logvar_q, mu_p, logvar_p sums * mean_scale) or NULL.        */
+int vae_gauss_pair_fwd(const void* enc_logits, int64_t stride_enc, const void* prior_logits, int64_t stride_prior,
+                       const void* noise_post, const void* noise_prior, void* z_post, void* z_prior,
+                       void* logvar_post, void* logvar_prior, void* clamped_prior_logits, void* kl_pair,
+                       void* kl_prior, float* means, float* workspace, int64_t B, int64_t L, float eps_tol,
+                       float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0, int dtype,
+                       vae_stream_t stream);
+/* Grads of every output (each may be NULL) -> g_enc_logits, g_prior_logits [B, 2L] (raw prior logits). */
+int vae_gauss_pair_bwd(const void* enc_logits, int64_t stride_enc, const void* prior_logits, int64_t stride_prior,
+                       const void* noise_post, const void* noise_prior, const void* gz_post, const void* gz_prior,
+                       const void* glogvar_post, const void* glogvar_prior, const void* gclamped, const void* gkl_pair,
+                       const void* gkl_prior, const float* gmeans, void* g_enc_logits, void* g_prior_logits,
+                       int64_t B, int64_t L, float eps_tol, float mean_scale, int training, uint64_t seed,
+                       uint64_t offset, int64_t row0, int dtype, vae_stream_t stream);
+
 /* ---- GumbelSoftmax ----------------------------------------------------------
  * reparameterizers/gumbel.py:110-124 (log_q_z = log_softmax(logits)), :257-278
  * (g = -log(-log(U + 1e-9) + 1e-9); y = softmax((logits + g)/tau + 1e-9); the

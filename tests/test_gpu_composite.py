@@ -186,3 +186,45 @@ def test_vrnn_time_batched_loss_vs_per_step_oracle():
             close(out[k], v, rtol=1e-5, atol=1e-3)
         else:
             assert out[k] == pytest.approx(v)
+
+
+@pytest.mark.parametrize('B,L', [(5, 3), (64, 128), (1000, 36), (257, 512)])
+@pytest.mark.parametrize('train', [True, False])
+def test_vrnn_fused_pair_backward_vs_oracle(B, L, train):
+    """The fused per-step kernel (both draws + clamp + both KLs): values and all input gradients."""
+    from vae_amd import vrnn as V
+    from vae_amd.reparameterizers import IsotropicGaussian
+    torch.manual_seed(B + L)
+    c = cfg(continuous_size=2 * L)
+    rep = IsotropicGaussian(c)
+    rep.train(train)
+    enc, pri = torch.randn(B, 2 * L), torch.randn(B, 2 * L)
+    n1, n2 = torch.randn(B, L), torch.randn(B, L)
+    w1, w2, w3 = torch.randn(B, L), torch.randn(B, L), torch.randn(B)
+
+    ec, pc = enc.clone().requires_grad_(True), pri.clone().requires_grad_(True)
+    z0, p0 = O.vrnn_reparameterize(ec, pc, n1, n2, training=train)
+    k0 = O.vrnn_kld(p0, True)
+    obj0 = (z0['posterior'] * w1).sum() + (z0['prior'] * w2).sum() + (k0 * w3).sum() \
+        + p0['prior']['gaussian']['logvar_mean'] + 2 * p0['posterior']['gaussian']['mu_mean'] \
+        + (p0['prior']['gaussian']['logvar'] * w1).sum() + (p0['prior']['logits'] * torch.cat([w2, w1], -1)).sum()
+    g0 = torch.autograd.grad(obj0, [ec, pc])
+
+    ed, pd = enc.to(DEV).requires_grad_(True), pri.to(DEV).requires_grad_(True)
+    lm = {'encoder_logits': ed, 'prior_logits': pd, 'x_features': None}
+    z1, p1 = V.reparameterize(rep, lm, c, noise=(n1.to(DEV), n2.to(DEV)))
+    k1 = V.kld(rep, p1, {'use_prior_kl': True})
+    w1d, w2d, w3d = w1.to(DEV), w2.to(DEV), w3.to(DEV)
+    obj1 = (z1['posterior'] * w1d).sum() + (z1['prior'] * w2d).sum() + (k1 * w3d).sum() \
+        + p1['prior']['gaussian']['logvar_mean'] + 2 * p1['posterior']['gaussian']['mu_mean'] \
+        + (p1['prior']['gaussian']['logvar'] * w1d).sum() + (p1['prior']['logits'] * torch.cat([w2d, w1d], -1)).sum()
+    g1 = torch.autograd.grad(obj1, [ed, pd])
+    assert torch.equal(z1['posterior'].detach().cpu(), z0['posterior'].detach())
+    close(z1['prior'], z0['prior'], rtol=1e-6, atol=1e-6)
+    close(k1, k0, rtol=1e-5, atol=1e-5 * L)
+    close(V.kld(rep, p1, {'use_prior_kl': False}), O.vrnn_kld(p0, False), rtol=1e-5, atol=1e-5 * L)
+    close(g1[0], g0[0], rtol=1e-4, atol=1e-5)
+    close(g1[1], g0[1], rtol=1e-4, atol=1e-5)
+    # kl() against a DIFFERENT prior must not reuse the fused pair value
+    other = {'gaussian': {'mu': torch.zeros(B, L, device=DEV), 'logvar': torch.ones(B, L, device=DEV)}}
+    close(rep.kl(p1['posterior'], other), O.gauss_kl(p0['posterior']), rtol=1e-5, atol=1e-5 * L)

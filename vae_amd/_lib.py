@@ -30,6 +30,10 @@ SIGNATURES = {
     'vae_gauss_reparam_kl_bwd': [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _f, _f, _i, _u64, _u64, _i64, _i, _p],
     'vae_gauss_kl_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i, _p],
     'vae_gauss_kl_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
+    'vae_gauss_pair_fwd': [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f, _f, _i,
+                           _u64, _u64, _i64, _i, _p],
+    'vae_gauss_pair_bwd': [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f, _f,
+                           _i, _u64, _u64, _i64, _i, _p],
     'vae_gumbel_fwd': [_p, _i64, _p, _p, _p, _p, _i64, _i64, _f, _u64, _u64, _i64, _i, _p],
     'vae_gumbel_bwd': [_p, _p, _p, _p, _p, _p, _i64, _i64, _f, _i, _p],
     'vae_categorical_kl_fwd': [_p, _i64, _p, _i64, _p, _i64, _i64, _i, _p],

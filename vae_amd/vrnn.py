@@ -11,7 +11,9 @@ equals the reference's `_add_loss_map` / `_mean_map` because every step holds th
 import torch
 
 from . import functional as F_
+from . import rng
 from .elbo import _pack
+from .reparameterizers.isotropic_gaussian import EPS_TOL, IsotropicGaussian
 
 
 def clamp_variance(logits, config, reparameterizer=None):
@@ -28,16 +30,51 @@ def clamp_variance(logits, config, reparameterizer=None):
 
 def reparameterize(reparameterizer, logits_map, config, noise=None):
     """vrnn.py:419-447.  `noise` = (posterior noise, prior noise) for injection, else in-kernel Philox;
-    both draws consume the generator in the reference's order (posterior first)."""
+    both draws consume the generator in the reference's order (posterior first).
+
+    With an IsotropicGaussian reparameterizer on 2-D logits the whole step -- both draws, the variance
+    clamp and both KLs -- is ONE fused launch (`functional.gauss_pair`); the KLs ride on the returned
+    logvar tensors so that `kld()` below costs nothing.  Anything else takes the generic two-call path."""
     noise = (None, None) if noise is None else noise
+    enc, pri = logits_map['encoder_logits'], logits_map['prior_logits']
+    if isinstance(reparameterizer, IsotropicGaussian) and config['reparam_type'] == 'isotropic_gaussian' \
+            and enc.dim() == 2 and pri.dim() == 2:
+        return _reparameterize_fused(reparameterizer, logits_map, config, noise)
     kw = {} if noise[0] is None else {'noise': noise[0]}
-    z_enc_t, params_enc_t = reparameterizer(logits_map['encoder_logits'], **kw)
-    logits_map['prior_logits'] = clamp_variance(logits_map['prior_logits'], config, reparameterizer)
+    z_enc_t, params_enc_t = reparameterizer(enc, **kw)
+    logits_map['prior_logits'] = clamp_variance(pri, config, reparameterizer)
     kw = {} if noise[1] is None else {'noise': noise[1]}
     z_prior_t, params_prior_t = reparameterizer(logits_map['prior_logits'], **kw)
     z = {'prior': z_prior_t, 'posterior': z_enc_t, 'x_features': logits_map['x_features']}
     params = {'prior': params_prior_t, 'posterior': params_enc_t}
     return z, params
+
+
+def _reparameterize_fused(rep, logits_map, config, noise):
+    enc, pri = logits_map['encoder_logits'], logits_map['prior_logits']
+    L = rep.output_size
+    assert enc.shape[-1] == 2 * L and pri.shape[-1] == 2 * L
+    training = bool(rep.training)
+    seed, offset = (0, 0)
+    if training and (noise[0] is None or noise[1] is None):
+        seed, offset = rng.next_call()
+    z_q, z_p, lv_q, lv_p, clamped, kl_pair, kl_prior, means = F_.gauss_pair(
+        enc, pri, noise[0], noise[1], eps_tol=EPS_TOL, training=training, with_prior_kl=True, seed=seed,
+        offset=offset, row0=rep.row_offset, mean_scale=rep.mean_scale)
+    mu_q = torch.narrow(enc, -1, 0, L)
+    mu_p = torch.narrow(clamped, -1, 0, L)
+    if not training:
+        z_q, z_p = mu_q, mu_p
+    means = means.to(enc.dtype)
+    lv_q._vae_amd_kl_pair = (kl_pair, lv_p)      # KL(post || prior), valid against exactly this prior
+    lv_p._vae_amd_kl = (kl_prior, mu_p)          # KL(prior || N(0,1))
+    logits_map['prior_logits'] = clamped
+    params_q = {'z': z_q, 'logits': enc,
+                'gaussian': {'z': z_q, 'mu': mu_q, 'logvar': lv_q, 'mu_mean': means[0], 'logvar_mean': means[1]}}
+    params_p = {'z': z_p, 'logits': clamped,
+                'gaussian': {'z': z_p, 'mu': mu_p, 'logvar': lv_p, 'mu_mean': means[2], 'logvar_mean': means[3]}}
+    z = {'prior': z_p, 'posterior': z_q, 'x_features': logits_map['x_features']}
+    return z, {'prior': params_p, 'posterior': params_q}
 
 
 def kld(reparameterizer, dist, config):
