@@ -84,12 +84,30 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
                              % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # one rank per GPU; BENCH_BACKEND=gloo + fewer GPUs than ranks is a rehearsal mode for 1-GPU boxes only
+    backend = os.environ.get('BENCH_BACKEND', 'nccl')
+    ndev = torch.cuda.device_count()
+    if backend == 'nccl' and local_rank >= ndev:
+        raise SystemExit('bench.py: rank %d has no GPU (%d visible)' % (local_rank, ndev))
+    dev = torch.device('cuda', local_rank % max(ndev, 1))
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    def all_reduce(t, op=None):
+        # RCCL reduces device tensors in place; the gloo rehearsal goes through the host
+        op = dist.ReduceOp.SUM if op is None else op
+        if backend == 'nccl':
+            dist.all_reduce(t, op=op)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
 
     from vae_amd import _lib
     from vae_amd._lib import call, ptr
@@ -137,7 +155,7 @@ def main():
              ptr(elbo), ptr(scalars), ptr(ws), B, D, 0, st)
         mark(2)
         if dist is not None:
-            dist.all_reduce(scalars)          # global-batch means (abstract_vae.py:381-387) in one message
+            all_reduce(scalars)               # global-batch means (abstract_vae.py:381-387) in one message
         mark(3)
         call('vae_nll_elbo_bwd', ptr(x), ptr(recon), 0, None, None, None, ptr(gmeans), 1.0, inv_count, ptr(grecon),
              ptr(gkld), None, None, B, D, 0, st)
@@ -164,7 +182,7 @@ def main():
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     # per-kernel average durations from the HIP events recorded on the launch stream during the timed steps
