@@ -89,17 +89,18 @@ struct VecOf {
 #define VAE_NT_STORE 0
 #endif
 
-template <typename T, int V>
+template <typename T, int V, bool NT = (VAE_NT_LOAD != 0)>
 __device__ __forceinline__ void load_vec(const T* __restrict__ p, float (&out)[V]) {
   if constexpr (V == 1) {
     out[0] = to_f32(p[0]);
   } else {
     typedef typename PackOf<T, V>::type P;
-#if VAE_NT_LOAD
-    const P raw = __builtin_nontemporal_load(reinterpret_cast<const P*>(p));
-#else
-    const P raw = *reinterpret_cast<const P*>(p);
-#endif
+    P raw;
+    if constexpr (NT) {
+      raw = __builtin_nontemporal_load(reinterpret_cast<const P*>(p));
+    } else {
+      raw = *reinterpret_cast<const P*>(p);
+    }
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
       for (int i = 0; i < V; ++i) out[i] = raw[i];
@@ -141,13 +142,13 @@ __device__ __forceinline__ void store_vec(T* __restrict__ p, const float (&in)[V
 // (always a valid address, an L1 hit, masked by the caller with `j < nvec`), so the loads carry
 // no branch and the compiler batches them under one counted s_waitcnt: 16*U bytes per tensor
 // in flight per lane, which is what keeps HBM busy at 8 waves/SIMD.
-template <typename T, int V, int U>
+template <typename T, int V, int U, bool NT = (VAE_NT_LOAD != 0)>
 __device__ __forceinline__ void load_chunk(const T* __restrict__ base, int j0, int G, int nvec, float (&out)[U][V]) {
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     int j = j0 + u * G;
     j = j < nvec ? j : nvec - 1;
-    load_vec<T, V>(base + (int64_t)j * V, out[u]);
+    load_vec<T, V, NT>(base + (int64_t)j * V, out[u]);
   }
 }
 

@@ -21,6 +21,17 @@ namespace vae {
 
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 constexpr float kBin = 1.0f / 256.0f;
+// Load policy per kernel (tuning knobs).  Measured in the bench.py sequence (r01): temporal loads in any one of
+// the four hot kernels slow that kernel by 25-30 % and only shift ~10 % of time out of its successor; walking the
+// backward's rows in reverse (to hit what the forward left in the Infinity Cache) changed nothing -- nt loads do
+// not seem to allocate there.  All four stay non-temporal.
+#ifndef VAE_NT_NLL_FWD
+#define VAE_NT_NLL_FWD 1
+#endif
+#ifndef VAE_NT_NLL_BWD
+#define VAE_NT_NLL_BWD 1
+#endif
+constexpr bool kNtNllFwd = VAE_NT_NLL_FWD != 0, kNtNllBwd = VAE_NT_NLL_BWD != 0;
 
 __device__ __forceinline__ float sigmoidf_(float v) { return fast_rcp(1.0f + __expf(-v)); }
 // 1/d to ~0.5 ulp: v_rcp_f32 + one Newton step (3 instructions instead of the ~10 of an IEEE divide)
@@ -113,9 +124,9 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_fwd_kernel(
       const T* rr = recon + row * rstride;
       for (int j0 = sub; j0 < nvec; j0 += G * U) {
         float xv[U][V], a[U][V], b[U][V];
-        load_chunk<T, V, U>(xr, j0, G, nvec, xv);
-        load_chunk<T, V, U>(rr, j0, G, nvec, a);
-        if constexpr (NLL != VAE_NLL_BERNOULLI) load_chunk<T, V, U>(rr + D, j0, G, nvec, b);
+        load_chunk<T, V, U, kNtNllFwd>(xr, j0, G, nvec, xv);
+        load_chunk<T, V, U, kNtNllFwd>(rr, j0, G, nvec, a);
+        if constexpr (NLL != VAE_NLL_BERNOULLI) load_chunk<T, V, U, kNtNllFwd>(rr + D, j0, G, nvec, b);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           float su = 0.f;
@@ -184,9 +195,9 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_bwd_kernel(
     T* gr = grecon + row * rstride;
     for (int j0 = sub; j0 < nvec; j0 += G * U) {
       float xv[U][V], a[U][V], b[U][V];
-      load_chunk<T, V, U>(xr, j0, G, nvec, xv);
-      load_chunk<T, V, U>(rr, j0, G, nvec, a);
-      if constexpr (NLL != VAE_NLL_BERNOULLI) load_chunk<T, V, U>(rr + D, j0, G, nvec, b);
+      load_chunk<T, V, U, kNtNllBwd>(xr, j0, G, nvec, xv);
+      load_chunk<T, V, U, kNtNllBwd>(rr, j0, G, nvec, a);
+      if constexpr (NLL != VAE_NLL_BERNOULLI) load_chunk<T, V, U, kNtNllBwd>(rr + D, j0, G, nvec, b);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int j = j0 + u * G;

@@ -16,6 +16,14 @@
 
 namespace vae {
 
+#ifndef VAE_NT_GAUSS_FWD
+#define VAE_NT_GAUSS_FWD 1
+#endif
+#ifndef VAE_NT_GAUSS_BWD
+#define VAE_NT_GAUSS_BWD 1
+#endif
+constexpr bool kNtGaussFwd = VAE_NT_GAUSS_FWD != 0, kNtGaussBwd = VAE_NT_GAUSS_BWD != 0;
+
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
@@ -37,9 +45,9 @@ __global__ __launch_bounds__(kBlock) void gauss_fwd_kernel(
       const T* lrow = logits + row * row_stride;
       for (int j0 = sub; j0 < nvec; j0 += G * U) {
         float mu[U][V], s[U][V], e[U][V];
-        load_chunk<T, V, U>(lrow, j0, G, nvec, mu);
-        load_chunk<T, V, U>(lrow + L, j0, G, nvec, s);
-        if (training && noise) load_chunk<T, V, U>(noise + row * L, j0, G, nvec, e);
+        load_chunk<T, V, U, kNtGaussFwd>(lrow, j0, G, nvec, mu);
+        load_chunk<T, V, U, kNtGaussFwd>(lrow + L, j0, G, nvec, s);
+        if (training && noise) load_chunk<T, V, U, kNtGaussFwd>(noise + row * L, j0, G, nvec, e);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int j = j0 + u * G;
@@ -99,11 +107,11 @@ __global__ __launch_bounds__(kBlock) void gauss_bwd_kernel(
     const float gk = gkl ? to_f32(gkl[row]) : 0.f;
     for (int j0 = sub; j0 < nvec; j0 += G * U) {
       float mu[U][V], s[U][V], e[U][V], g[U][V], g2[U][V];
-      load_chunk<T, V, U>(lrow, j0, G, nvec, mu);
-      load_chunk<T, V, U>(lrow + L, j0, G, nvec, s);
-      if (gz) load_chunk<T, V, U>(gz + row * L, j0, G, nvec, g);
-      if (gs) load_chunk<T, V, U>(gs + row * L, j0, G, nvec, g2);
-      if (use_e && noise) load_chunk<T, V, U>(noise + row * L, j0, G, nvec, e);
+      load_chunk<T, V, U, kNtGaussBwd>(lrow, j0, G, nvec, mu);
+      load_chunk<T, V, U, kNtGaussBwd>(lrow + L, j0, G, nvec, s);
+      if (gz) load_chunk<T, V, U, kNtGaussBwd>(gz + row * L, j0, G, nvec, g);
+      if (gs) load_chunk<T, V, U, kNtGaussBwd>(gs + row * L, j0, G, nvec, g2);
+      if (use_e && noise) load_chunk<T, V, U, kNtGaussBwd>(noise + row * L, j0, G, nvec, e);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int j = j0 + u * G;
