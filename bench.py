@@ -193,6 +193,37 @@ def main():
     if not (sanity == sanity):
         raise SystemExit('bench: loss_mean is NaN')
 
+    # the same step through the drop-in classes (autograd Functions, torch allocator): not the timed region,
+    # reported beside it so the cost of the Python boundary is visible
+    module_path = None
+    if world == 1:
+        from vae_amd.reparameterizers import IsotropicGaussian
+        from vae_amd.elbo import loss_function
+        mod = IsotropicGaussian({'continuous_size': 2 * L, 'cuda': True, 'half': False})
+        mod.train()
+        lg = logits.detach().requires_grad_(True)
+        rc = recon.view(B, C, H, W).detach().requires_grad_(True)
+        xi = x.view(B, C, H, W)
+
+        def mstep():
+            zz, params = mod(lg, noise=noise)
+            out = loss_function(rc, xi, mod.kl(params), 'bernoulli')
+            torch.autograd.backward([out['loss_mean'], zz], [None, gz])
+            lg.grad = None
+            rc.grad = None
+        for _ in range(5):
+            mstep()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(20):
+            mstep()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        mms = e0.elapsed_time(e1) / 20
+        module_path = {'ms_per_step': round(mms, 4), 'samples_per_s': B / (mms * 1e-3),
+                       'what': 'IsotropicGaussian.forward + .kl + elbo.loss_function + autograd backward, 20 steps'}
+
     if rank == 0:
         ab = algorithmic_bytes(B)
         kernels = {}
@@ -225,6 +256,7 @@ def main():
                          'achieved_GBs': round(total_bytes / (ksum * 1e-3) / 1e9, 1),
                          'frac': round(total_bytes / (ksum * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             'loss_mean': sanity,
+            'module_path': module_path,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

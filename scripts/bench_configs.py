@@ -70,6 +70,19 @@ def gauss_pair(B, L):
     timeit('gauss_kl_bwd', cfg, lambda: call('vae_gauss_kl_bwd', ptr(mq), L, ptr(sq), L, ptr(mp), L, ptr(sp), L, ptr(gkl), ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(g[3]), B, L, 0, st), B * (32 * L + 4))
 
 
+def pair_fused(B, L):
+    enc, pri, n1, n2 = T(B, 2 * L), T(B, 2 * L), T(B, L), T(B, L)
+    zq, zp, lvq, lvp, cl = T(B, L, kind='e'), T(B, L, kind='e'), T(B, L, kind='e'), T(B, L, kind='e'), T(B, 2 * L, kind='e')
+    klp, kl0, gk = T(B, kind='e'), T(B, kind='e'), T(B)
+    means = torch.zeros(4, device=dev)
+    ge, gp = T(B, 2 * L, kind='e'), T(B, 2 * L, kind='e')
+    cfg = 'B=%d L=%d f32 (one VRNN step, fused)' % (B, L)
+    timeit('gauss_pair_fwd', cfg, lambda: call('vae_gauss_pair_fwd', ptr(enc), 2 * L, ptr(pri), 2 * L, ptr(n1), ptr(n2), ptr(zq), ptr(zp), ptr(lvq), ptr(lvp), ptr(cl), ptr(klp), ptr(kl0), ptr(means), ptr(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st),
+           B * (40 * L + 4))   # SURVEY: 2 logits 16L + 2 noise 8L + 2 z 8L + clamped prior logits 8L + kl
+    timeit('gauss_pair_bwd', cfg, lambda: call('vae_gauss_pair_bwd', ptr(enc), 2 * L, ptr(pri), 2 * L, ptr(n1), ptr(n2), ptr(zq), ptr(zp), None, None, None, ptr(gk), ptr(gk), None, ptr(ge), ptr(gp), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st),
+           B * (48 * L + 8))   # 2 logits 16L + 2 noise 8L + 2 gz 8L + 2 glogits 16L
+
+
 def gumbel(B, K, philox=False):
     logits, U = T(B, K), T(B, K, kind='rand')
     y, zh, lq, gy, gl = [T(B, K, kind='e') for _ in range(5)]
@@ -162,6 +175,8 @@ if __name__ == '__main__':
     print('== C5: VRNN per-step pair (B per step) and the time-batched loss (T*B rows)')
     gauss(16384, 128)
     gauss_pair(16384, 128)
+    pair_fused(16384, 128)
+    pair_fused(4096, 32)
     nll(64 * 1024, 784, 0, 'bernoulli T=64 x B=1024')
     print('== Bernoulli / Beta reparameterizers')
     bernoulli(65536, 1024)

@@ -64,7 +64,9 @@ def test_beta_vs_oracle(B, L):
     (g1,) = torch.autograd.grad((k1 * w.to(DEV)).sum() + 5 * p['beta']['conc1_mean'], lg, retain_graph=True)
     close(p['beta']['conc1'], bp['conc1'], rtol=1e-6, atol=1e-7)
     close(k1, k0, rtol=2e-5, atol=1e-4)
-    close(g1, g0, rtol=1e-4, atol=1e-5)
+    # d KL / d logit = s(1-s) [(a - 1.1) psi'(a) + (2.2 - a1 - a0) psi'(a1 + a0)]: two O(1..1e3) terms of opposite
+    # sign; fp32 (kernel and oracle alike) keeps ~1e-6 of the terms, not of their difference
+    close(g1, g0, rtol=1e-4, atol=1e-4)
     # the sample's gradient reaches the logits through the kernel's backward (rsample is torch's)
     (gz,) = torch.autograd.grad(z.sum(), lg)
     assert torch.isfinite(gz).all() and float(gz.abs().sum()) > 0

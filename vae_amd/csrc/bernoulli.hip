@@ -26,7 +26,7 @@ struct ClampEps<bf16_t> {
 };
 constexpr float kBernKlEps = 1e-6f;
 
-__device__ __forceinline__ float sigmoid_div(float v) { return 1.0f / (1.0f + expf(-v)); }
+__device__ __forceinline__ float sigmoid_div(float v) { return rcp_nr(1.0f + expf(-v)); }
 
 template <typename T, int V, int U>
 __global__ __launch_bounds__(kBlock) void bernoulli_fwd_kernel(
@@ -38,6 +38,7 @@ __global__ __launch_bounds__(kBlock) void bernoulli_fwd_kernel(
   const int rloc = threadIdx.x / G;
   const int nvec = K / V;
   constexpr float e = ClampEps<T>::v;
+  const float itau = 1.0f / tau;
   for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
     const int64_t row = t * rpb + rloc;
     if (row >= B) continue;
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void bernoulli_fwd_kernel(
           for (int i = 0; i < V; ++i) {
             const float p = fminf(fmaxf(to_f32(from_f32<T>(sigmoid_div(l[k][i]))), e), 1.0f - e);
             const float uu = fminf(fmaxf(u[k][i], e), 1.0f - e);
-            const float lg = (logf(uu) - log1pf(-uu) + logf(p) - log1pf(-p)) / tau;
+            const float lg = (__logf(uu) - __logf(1.0f - uu) + __logf(p) - __logf(1.0f - p)) * itau;
             y[i] = to_f32(from_f32<T>(sigmoid_div(lg)));
             const float h = y[i] >= 0.5f ? 1.0f : 0.0f;
             zh[i] = add_rn(to_f32(from_f32<T>(sub_rn(h, y[i]))), y[i]);
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(kBlock) void bernoulli_kl_kernel(
     float acc = 0.f;
     if (row < B) {
       const float gk = BWD ? to_f32(gkl[row]) : 0.f;
+      const float lhalf = __logf(0.5f + kBernKlEps);  // both prior terms when no prior logits are given
       for (int j0 = sub; j0 < nvec; j0 += G * U) {
         float a[U][V], b[U][V];
         load_chunk<T, V, U>(lq + row * stride_q, j0, G, nvec, a);
@@ -134,14 +136,14 @@ __global__ __launch_bounds__(kBlock) void bernoulli_kl_kernel(
             for (int i = 0; i < V; ++i) {
               const float q1 = sigmoid_div(a[k][i]), q0 = 1.0f - q1;
               const float p1 = lp ? sigmoid_div(b[k][i]) : 0.5f, p0 = 1.0f - p1;
-              const float d1 = logf(q1 + kBernKlEps) - logf(p1 + kBernKlEps);
-              const float d0 = logf(q0 + kBernKlEps) - logf(p0 + kBernKlEps);
+              const float d1 = __logf(q1 + kBernKlEps) - (lp ? __logf(p1 + kBernKlEps) : lhalf);
+              const float d0 = __logf(q0 + kBernKlEps) - (lp ? __logf(p0 + kBernKlEps) : lhalf);
               if constexpr (!BWD) {
                 acc += q1 * d1 + q0 * d0;
               } else {
-                const float dq1 = d1 + q1 / (q1 + kBernKlEps) - d0 - q0 / (q0 + kBernKlEps);
+                const float dq1 = d1 + q1 * fast_rcp(q1 + kBernKlEps) - d0 - q0 * fast_rcp(q0 + kBernKlEps);
                 oq[i] = gk * dq1 * q1 * q0;
-                op[i] = gk * (q0 / (p0 + kBernKlEps) - q1 / (p1 + kBernKlEps)) * p1 * p0;
+                op[i] = gk * (q0 * fast_rcp(p0 + kBernKlEps) - q1 * fast_rcp(p1 + kBernKlEps)) * p1 * p0;
               }
             }
             if constexpr (BWD) {

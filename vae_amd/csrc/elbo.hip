@@ -34,11 +34,6 @@ constexpr float kBin = 1.0f / 256.0f;
 constexpr bool kNtNllFwd = VAE_NT_NLL_FWD != 0, kNtNllBwd = VAE_NT_NLL_BWD != 0;
 
 __device__ __forceinline__ float sigmoidf_(float v) { return fast_rcp(1.0f + __expf(-v)); }
-// 1/d to ~0.5 ulp: v_rcp_f32 + one Newton step (3 instructions instead of the ~10 of an IEEE divide)
-__device__ __forceinline__ float rcp_nr(float d) {
-  const float r = fast_rcp(d);
-  return r * (2.0f - d * r);
-}
 // sigmoid for the discretized logistic, whose two CDF values are subtracted from each other (an
 // ulp there is amplified by 1/P): accurate exp, near-correctly-rounded reciprocal.
 __device__ __forceinline__ float sigmoid_acc(float v) { return rcp_nr(1.0f + expf(-v)); }

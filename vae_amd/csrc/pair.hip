@@ -16,7 +16,7 @@ namespace vae {
 
 constexpr uint64_t kPriorStream = 0x8000000000000000ull;  // Philox stream id of the prior's draw
 
-__device__ __forceinline__ float sigmoid_p(float v) { return 1.0f / (1.0f + expf(-v)); }
+__device__ __forceinline__ float sigmoid_p(float v) { return rcp_nr(1.0f + expf(-v)); }
 
 template <typename T, int V, int U>
 __global__ __launch_bounds__(kBlock) void gauss_pair_fwd_kernel(
@@ -66,9 +66,10 @@ __global__ __launch_bounds__(kBlock) void gauss_pair_fwd_kernel(
                 zp[i] = add_rn(to_f32(from_f32<T>(mul_rn(ep[u][i], to_f32(from_f32<T>(mul_rn(0.5f, lp)))))), b);
               }
               // torch kl_normal_normal: var_ratio = (lq/lp)^2, t1 = ((a - b)/lp)^2
-              const float r = lq / lp;
+              const float ip = rcp_nr(lp);
+              const float r = lq * ip;
               const float vr = r * r;
-              const float d = (a - b) / lp;
+              const float d = (a - b) * ip;
               kp += 0.5f * (vr + d * d - 1.0f - __logf(vr));
               const float lp2 = lp * lp;
               k0 += 0.5f * (lp2 + b * b - 1.0f - __logf(lp2));
