@@ -148,7 +148,7 @@ def main():
             if ev is not None:
                 ev[i].record()
         mark(0)
-        call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, ptr(noise), ptr(z), ptr(logvar), ptr(kl), pmeans,
+        call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, ptr(noise), ptr(z), L, ptr(logvar), ptr(kl), pmeans,
              ptr(ws), B, L, 1e-6, mean_scale, 1, 0, 0, row0, 0, st)
         mark(1)
         call('vae_nll_elbo_fwd', ptr(x), ptr(recon), 0, ptr(kl), None, None, 1.0, inv_count, ptr(nll), ptr(loss),
@@ -160,8 +160,8 @@ def main():
         call('vae_nll_elbo_bwd', ptr(x), ptr(recon), 0, None, None, None, ptr(gmeans), 1.0, inv_count, ptr(grecon),
              ptr(gkld), None, None, B, D, 0, st)
         mark(4)
-        call('vae_gauss_reparam_kl_bwd', ptr(logits), 2 * L, ptr(noise), ptr(gz), None, ptr(gkld), None,
-             ptr(glogits), B, L, 1e-6, mean_scale, 1, 0, 0, row0, 0, st)
+        call('vae_gauss_reparam_kl_bwd', ptr(logits), 2 * L, ptr(noise), ptr(gz), L, None, ptr(gkld), None,
+             ptr(glogits), 2 * L, B, L, 1e-6, mean_scale, 1, 0, 0, row0, 0, st)
         mark(5)
 
     for _ in range(args.warmup):

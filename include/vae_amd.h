@@ -14,8 +14,10 @@
  *     buffer, calls are asynchronous on `stream` (a hipStream_t, 0 = default);
  *   - `dtype` selects the tensor element type (VAE_F32 / VAE_BF16); arithmetic and
  *     reductions are always fp32 inside the kernels;
- *   - rows are samples.  `row_stride` / `stride_*` are in ELEMENTS; tensors
- *     without a stride argument are contiguous;
+ *   - rows are samples.  `row_stride` / `stride_*` / `*_stride` are in ELEMENTS; tensors
+ *     without a stride argument are contiguous; an output / gradient stride of 0 means
+ *     contiguous too.  Output strides let ConcatReparameterizer children write straight into
+ *     the concatenated sample and into one shared d(logits) buffer (no cat / slice copies);
  *   - `workspace` is scratch of at least vae_workspace_bytes() bytes, ZEROED ONCE by the
  *     caller when it is created (the kernels leave its counters at zero again), used by one
  *     call at a time (per stream); the batch means are finished inside the producing kernel;
@@ -61,14 +63,15 @@ size_t vae_workspace_bytes(void);
  *   kl [B] in `dtype`; means: 2 floats (sum mu, sum logvar) * mean_scale, or NULL.
  *   mean_scale is 1/(B*L) on one GPU and 1/(B_global*L) when the batch is
  *   sharded (the caller then all-reduces the two floats).                        */
-int vae_gauss_reparam_kl_fwd(const void* logits, int64_t row_stride, const void* noise, void* z, void* s_out,
-                             void* kl, float* means, float* workspace, int64_t B, int64_t L, float eps_tol,
+int vae_gauss_reparam_kl_fwd(const void* logits, int64_t row_stride, const void* noise, void* z, int64_t z_stride,
+                             void* s_out, void* kl, float* means, float* workspace, int64_t B, int64_t L, float eps_tol,
                              float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0,
                              int dtype, vae_stream_t stream);
 /* Backward of the above: glogits [B, 2L] contiguous from gz [B, L], gs (grad of
  * the logvar output) [B, L], gkl [B], gmeans (2 floats); each grad may be NULL. */
 int vae_gauss_reparam_kl_bwd(const void* logits, int64_t row_stride, const void* noise, const void* gz,
-                             const void* gs, const void* gkl, const float* gmeans, void* glogits, int64_t B,
+                             int64_t gz_stride, const void* gs, const void* gkl, const float* gmeans, void* glogits,
+                             int64_t glogits_stride, int64_t B,
                              int64_t L, float eps_tol, float mean_scale, int training, uint64_t seed,
                              uint64_t offset, int64_t row0, int dtype, vae_stream_t stream);
 
@@ -115,13 +118,15 @@ int vae_gauss_pair_bwd(const void* enc_logits, int64_t stride_enc, const void* p
  *   logits [B, K] rows `row_stride` apart; unif [B, K] uniform draws or NULL
  *   (Philox keyed by (seed, offset, row0 + row, col)); y, z_hard, log_q_z [B, K].
  *   K <= VAE_MAX_SOFTMAX_ROW.                                                     */
-int vae_gumbel_fwd(const void* logits, int64_t row_stride, const void* unif, void* y, void* z_hard, void* log_q_z,
+int vae_gumbel_fwd(const void* logits, int64_t row_stride, const void* unif, void* y, int64_t y_stride, void* z_hard,
+                   int64_t z_hard_stride, void* log_q_z,
                    int64_t B, int64_t K, float tau, uint64_t seed, uint64_t offset, int64_t row0, int dtype,
                    vae_stream_t stream);
 /* glogits [B, K] from the grads of y, z_hard (straight-through: passes to y) and
  * log_q_z (each may be NULL), using the saved outputs y and log_q_z.              */
-int vae_gumbel_bwd(const void* y, const void* log_q_z, const void* gy, const void* gz_hard, const void* glog_q_z,
-                   void* glogits, int64_t B, int64_t K, float tau, int dtype, vae_stream_t stream);
+int vae_gumbel_bwd(const void* y, int64_t y_stride, const void* log_q_z, const void* gy, int64_t gy_stride,
+                   const void* gz_hard, int64_t gz_hard_stride, const void* glog_q_z, void* glogits,
+                   int64_t glogits_stride, int64_t B, int64_t K, float tau, int dtype, vae_stream_t stream);
 /* Categorical KL, reparameterizers/gumbel.py:222-254 (_kl_tf_version over two
  * OneHotCategorical(logits=log_q_z)): kl[b] = sum softmax(q)*(log_softmax(q) -
  * log_softmax(p)).  log_q / log_p: strided [B, K] views; g_log_p may be NULL.     */
@@ -135,11 +140,13 @@ int vae_categorical_kl_bwd(const void* log_q, int64_t stride_q, const void* log_
  * (p = clamp(sigmoid(l)), u = clamp(U), y = sigmoid((log u - log1p(-u) + log p - log1p(-p))/tau)),
  * bernoulli.py:111-124 (hard = y >= 0.5; z_hard = (hard - y).detach() + y).
  *   logits [B, K] rows `row_stride` apart; unif [B, K] or NULL (Philox); y, z_hard [B, K].  */
-int vae_bernoulli_fwd(const void* logits, int64_t row_stride, const void* unif, void* y, void* z_hard, int64_t B,
+int vae_bernoulli_fwd(const void* logits, int64_t row_stride, const void* unif, void* y, int64_t y_stride, void* z_hard,
+                      int64_t z_hard_stride, int64_t B,
                       int64_t K, float tau, uint64_t seed, uint64_t offset, int64_t row0, int dtype,
                       vae_stream_t stream);
-int vae_bernoulli_bwd(const void* logits, int64_t row_stride, const void* y, const void* gy, const void* gz_hard,
-                      void* glogits, int64_t B, int64_t K, float tau, int dtype, vae_stream_t stream);
+int vae_bernoulli_bwd(const void* logits, int64_t row_stride, const void* y, int64_t y_stride, const void* gy,
+                      int64_t gy_stride, const void* gz_hard, int64_t gz_hard_stride, void* glogits,
+                      int64_t glogits_stride, int64_t B, int64_t K, float tau, int dtype, vae_stream_t stream);
 /* bernoulli.py:147-191: sum over the last dim of q1*(log(q1+1e-6) - log(p1+1e-6)) +
  * q0*(log(q0+1e-6) - log(p0+1e-6)); logits_p NULL = the uniform prior p = 0.5.     */
 int vae_bernoulli_kl_fwd(const void* logits_q, int64_t stride_q, const void* logits_p, int64_t stride_p, void* kl,

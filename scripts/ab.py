@@ -44,10 +44,10 @@ for path in libs:
 
 def kernels(lib):
     return {
-        'gauss_fwd': (lambda: lib.vae_gauss_reparam_kl_fwd(p(logits), 2 * L, p(noise), p(z), p(logvar), p(kl), p(scal), p(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, DC, st), (4 * L * ES + ES) * B),
-        'gauss_fwd_nomeans': (lambda: lib.vae_gauss_reparam_kl_fwd(p(logits), 2 * L, p(noise), p(z), p(logvar), p(kl), None, p(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, DC, st), (4 * L * ES + ES) * B),
-        'gauss_fwd_nologvar': (lambda: lib.vae_gauss_reparam_kl_fwd(p(logits), 2 * L, p(noise), p(z), None, p(kl), p(scal), p(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, DC, st), (4 * L * ES + ES) * B),
-        'gauss_bwd': (lambda: lib.vae_gauss_reparam_kl_bwd(p(logits), 2 * L, p(noise), p(gz), None, p(gkld), None, p(glogits), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, DC, st), (6 * L * ES + ES) * B),
+        'gauss_fwd': (lambda: lib.vae_gauss_reparam_kl_fwd(p(logits), 2 * L, p(noise), p(z), 0, p(logvar), p(kl), p(scal), p(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, DC, st), (4 * L * ES + ES) * B),
+        'gauss_fwd_nomeans': (lambda: lib.vae_gauss_reparam_kl_fwd(p(logits), 2 * L, p(noise), p(z), 0, p(logvar), p(kl), None, p(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, DC, st), (4 * L * ES + ES) * B),
+        'gauss_fwd_nologvar': (lambda: lib.vae_gauss_reparam_kl_fwd(p(logits), 2 * L, p(noise), p(z), 0, None, p(kl), p(scal), p(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, DC, st), (4 * L * ES + ES) * B),
+        'gauss_bwd': (lambda: lib.vae_gauss_reparam_kl_bwd(p(logits), 2 * L, p(noise), p(gz), 0, None, p(gkld), None, p(glogits), 0, B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, DC, st), (6 * L * ES + ES) * B),
         'nll_fwd': (lambda: lib.vae_nll_elbo_fwd(p(x), p(recon), 0, p(kl), None, None, 1.0, 1.0 / B, p(nll), p(loss), p(elbo), p(scal), p(ws), B, D, DC, st), (2 * D + 3) * ES * B),
         'nll_bwd': (lambda: lib.vae_nll_elbo_bwd(p(x), p(recon), 0, None, None, None, p(gmeans), 1.0, 1.0 / B, p(grecon), p(gkld), None, None, B, D, DC, st), 3 * D * ES * B),
     }

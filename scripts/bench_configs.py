@@ -55,9 +55,9 @@ def gauss(B, L, dtype=torch.float32, philox=False):
     gl, means = T(B, 2 * L, dtype=dtype, kind='e'), torch.zeros(2, device=dev)
     n = None if philox else noise
     cfg = 'B=%d L=%d %s%s' % (B, L, 'bf16' if dc else 'f32', ' philox' if philox else '')
-    timeit('gauss_reparam_kl_fwd', cfg, lambda: call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, ptr(n), ptr(z), ptr(lv), ptr(kl), ptr(means), ptr(ws), B, L, 1e-6, 1.0 / (B * L), 1, 1, 1, 0, dc, st),
+    timeit('gauss_reparam_kl_fwd', cfg, lambda: call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, ptr(n), ptr(z), 0, ptr(lv), ptr(kl), ptr(means), ptr(ws), B, L, 1e-6, 1.0 / (B * L), 1, 1, 1, 0, dc, st),
            B * ((4 if philox else 5) * L * es + es) - B * L * es)  # SURVEY figure: logits + noise + z + kl (logvar write not counted)
-    timeit('gauss_reparam_kl_bwd', cfg, lambda: call('vae_gauss_reparam_kl_bwd', ptr(logits), 2 * L, ptr(n), ptr(gz), None, ptr(gkl), None, ptr(gl), B, L, 1e-6, 1.0 / (B * L), 1, 1, 1, 0, dc, st),
+    timeit('gauss_reparam_kl_bwd', cfg, lambda: call('vae_gauss_reparam_kl_bwd', ptr(logits), 2 * L, ptr(n), ptr(gz), 0, None, ptr(gkl), None, ptr(gl), 0, B, L, 1e-6, 1.0 / (B * L), 1, 1, 1, 0, dc, st),
            B * ((5 if philox else 6) * L * es + es))
 
 
@@ -89,8 +89,8 @@ def gumbel(B, K, philox=False):
     gy.normal_()
     u = None if philox else U
     cfg = 'B=%d K=%d f32%s' % (B, K, ' philox' if philox else '')
-    timeit('gumbel_fwd', cfg, lambda: call('vae_gumbel_fwd', ptr(logits), K, ptr(u), ptr(y), ptr(zh), ptr(lq), B, K, 0.7, 1, 1, 0, 0, st), B * ((16 if philox else 20) * K))
-    timeit('gumbel_bwd (gy only)', cfg, lambda: call('vae_gumbel_bwd', ptr(y), ptr(lq), ptr(gy), None, None, ptr(gl), B, K, 0.7, 0, st), B * 12 * K)
+    timeit('gumbel_fwd', cfg, lambda: call('vae_gumbel_fwd', ptr(logits), K, ptr(u), ptr(y), 0, ptr(zh), 0, ptr(lq), B, K, 0.7, 1, 1, 0, 0, st), B * ((16 if philox else 20) * K))
+    timeit('gumbel_bwd (gy only)', cfg, lambda: call('vae_gumbel_bwd', ptr(y), 0, ptr(lq), ptr(gy), 0, None, 0, None, ptr(gl), 0, B, K, 0.7, 0, st), B * 12 * K)
     kl, gkl = T(B, kind='e'), T(B)
     timeit('categorical_kl_fwd', cfg, lambda: call('vae_categorical_kl_fwd', ptr(lq), K, ptr(logits), K, ptr(kl), B, K, 0, st), B * (8 * K + 4))
     timeit('categorical_kl_bwd', cfg, lambda: call('vae_categorical_kl_bwd', ptr(lq), K, ptr(logits), K, ptr(gkl), ptr(y), ptr(zh), B, K, 0, st), B * (16 * K + 4))
@@ -104,8 +104,8 @@ def concat(B, L, K):
     disc = ctypes.c_void_p(logits.data_ptr() + 2 * L * 4)
 
     def fn():
-        call('vae_gauss_reparam_kl_fwd', ptr(logits), W, ptr(noise), ptr(z), ptr(lv), ptr(kl), ptr(means), ptr(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st)
-        call('vae_gumbel_fwd', disc, W, ptr(U), ptr(y), ptr(zh), ptr(lq), B, K, 1.0, 0, 0, 0, 0, st)
+        call('vae_gauss_reparam_kl_fwd', ptr(logits), W, ptr(noise), ptr(z), 0, ptr(lv), ptr(kl), ptr(means), ptr(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st)
+        call('vae_gumbel_fwd', disc, W, ptr(U), ptr(y), 0, ptr(zh), 0, ptr(lq), B, K, 1.0, 0, 0, 0, 0, st)
     timeit('concat fwd (gauss+gumbel)', 'B=%d L=%d K=%d f32, strided views of one logits buffer' % (B, L, K), fn, B * (16 * L + 4 + 20 * K))
 
 
@@ -113,8 +113,8 @@ def bernoulli(B, K):
     logits, U, gy = T(B, K), T(B, K, kind='rand'), T(B, K)
     y, zh, gl, kl, gkl = T(B, K, kind='e'), T(B, K, kind='e'), T(B, K, kind='e'), T(B, kind='e'), T(B)
     cfg = 'B=%d K=%d f32' % (B, K)
-    timeit('bernoulli_fwd', cfg, lambda: call('vae_bernoulli_fwd', ptr(logits), K, ptr(U), ptr(y), ptr(zh), B, K, 0.7, 0, 0, 0, 0, st), B * 16 * K)
-    timeit('bernoulli_bwd', cfg, lambda: call('vae_bernoulli_bwd', ptr(logits), K, ptr(y), ptr(gy), None, ptr(gl), B, K, 0.7, 0, st), B * 16 * K)
+    timeit('bernoulli_fwd', cfg, lambda: call('vae_bernoulli_fwd', ptr(logits), K, ptr(U), ptr(y), 0, ptr(zh), 0, B, K, 0.7, 0, 0, 0, 0, st), B * 16 * K)
+    timeit('bernoulli_bwd', cfg, lambda: call('vae_bernoulli_bwd', ptr(logits), K, ptr(y), 0, ptr(gy), 0, None, 0, ptr(gl), 0, B, K, 0.7, 0, st), B * 16 * K)
     timeit('bernoulli_kl_fwd', cfg, lambda: call('vae_bernoulli_kl_fwd', ptr(logits), K, None, 0, ptr(kl), B, K, 0, st), B * (4 * K + 4))
     timeit('bernoulli_kl_bwd', cfg, lambda: call('vae_bernoulli_kl_bwd', ptr(logits), K, None, 0, ptr(gkl), ptr(gl), None, B, K, 0, st), B * (8 * K + 4))
 

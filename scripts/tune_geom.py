@@ -18,9 +18,9 @@ scal = torch.zeros(8, **f32); gmeans = torch.zeros(6, **f32); gmeans[0] = 1
 grecon = torch.empty(B, D, **f32); gkld = torch.empty(B, **f32); glogits = torch.empty(B, 2 * L, **f32)
 ws = _lib.workspace(dev); st = _lib.stream_ptr(dev)
 ks = {
-    'gauss_fwd': (lambda: call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, ptr(noise), ptr(z), ptr(logvar), ptr(kl), ptr(scal), ptr(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st), (16 * L + 4) * B),
-    'gauss_fwd_philox': (lambda: call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, None, ptr(z), ptr(logvar), ptr(kl), ptr(scal), ptr(ws), B, L, 1e-6, 1.0 / (B * L), 1, 1, 1, 0, 0, st), (12 * L + 4) * B),
-    'gauss_bwd': (lambda: call('vae_gauss_reparam_kl_bwd', ptr(logits), 2 * L, ptr(noise), ptr(gz), None, ptr(gkld), None, ptr(glogits), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st), (24 * L + 4) * B),
+    'gauss_fwd': (lambda: call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, ptr(noise), ptr(z), 0, ptr(logvar), ptr(kl), ptr(scal), ptr(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st), (16 * L + 4) * B),
+    'gauss_fwd_philox': (lambda: call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, None, ptr(z), 0, ptr(logvar), ptr(kl), ptr(scal), ptr(ws), B, L, 1e-6, 1.0 / (B * L), 1, 1, 1, 0, 0, st), (12 * L + 4) * B),
+    'gauss_bwd': (lambda: call('vae_gauss_reparam_kl_bwd', ptr(logits), 2 * L, ptr(noise), ptr(gz), 0, None, ptr(gkld), None, ptr(glogits), 0, B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st), (24 * L + 4) * B),
     'nll_fwd': (lambda: call('vae_nll_elbo_fwd', ptr(x), ptr(recon), 0, ptr(kl), None, None, 1.0, 1.0 / B, ptr(nll), ptr(loss), ptr(elbo), ptr(scal), ptr(ws), B, D, 0, st), (8 * D + 12) * B),
     'nll_bwd': (lambda: call('vae_nll_elbo_bwd', ptr(x), ptr(recon), 0, None, None, None, ptr(gmeans), 1.0, 1.0 / B, ptr(grecon), ptr(gkld), None, None, B, D, 0, st), 12 * D * B),
 }

@@ -64,6 +64,82 @@ def test_concat_large_vs_oracle():
     close(m.kl(p1), O.concat_kl(p0, ['isotropic_gaussian', 'discrete']), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize('B,L,K,Kb', [(7, 3, 5, 2), (300, 64, 128, 32), (1025, 36, 10, 20), (64, 512, 1024, 8)])
+@pytest.mark.parametrize('train', [True, False])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_concat_fused_matches_per_child_path(B, L, K, Kb, train, dtype, monkeypatch):
+    """The one-node Concat (children write strided slices of shared buffers) against the per-child
+    path (narrow views + torch.cat) on the same injected noise: values and d(logits) bit-equal, since
+    both run the same kernels and only the addressing differs."""
+    from vae_amd.reparameterizers import ConcatReparameterizer, concat_reparameterizer as C
+    torch.manual_seed(B + L)
+    c = cfg(continuous_size=2 * L, discrete_size=K)
+    kinds = ['isotropic_gaussian', 'discrete', 'bernoulli']
+    W = 2 * L + K + K
+    logits = torch.randn(B, W, device=DEV).to(dtype)
+    noise = [torch.randn(B, L, device=DEV).to(dtype) if train else None,
+             torch.rand(B, K, device=DEV).clamp_(1e-3, 1 - 1e-3).to(dtype),
+             torch.rand(B, K, device=DEV).clamp_(1e-3, 1 - 1e-3).to(dtype)]
+    w = torch.randn(B, L + 2 * K, device=DEV).to(dtype)
+
+    def run(fused):
+        if not fused:
+            monkeypatch.setattr(C, '_FUSABLE', ())
+        m = ConcatReparameterizer(kinds, dict(c))
+        m.train(train)
+        x = logits.clone().requires_grad_(True)
+        z, params = m(x, noise=noise)
+        kl = m.kl(params)
+        extra = sum((p['discrete']['z_hard'].float() * 0.25).sum() + (p['z'].float() * 0.5).sum()
+                    for p in params['concat'] if 'discrete' in p)
+        extra = extra + params['concat'][1]['discrete']['log_q_z'].float().sum() * 0.125 \
+            + params['concat'][0]['gaussian']['logvar'].float().sum() * 0.0625 \
+            + params['concat'][0]['gaussian']['mu_mean'].float() + params['concat'][0]['gaussian']['logvar_mean'].float()
+        (g,) = torch.autograd.grad((z.float() * w.float()).sum() + kl.float().sum() + extra, x)
+        monkeypatch.undo()
+        return z, params, kl, g
+
+    z1, p1, kl1, g1 = run(True)
+    z0, p0, kl0, g0 = run(False)
+    assert z1.shape == (B, L + 2 * K) and z1.is_contiguous()
+    assert torch.equal(z1, z0) and torch.equal(kl1, kl0)
+    for a, b in zip(p1['concat'], p0['concat']):
+        assert set(a) == set(b)
+        assert torch.equal(a['z'], b['z']) and torch.equal(a['logits'], b['logits'])
+        if 'discrete' in a:
+            assert set(a['discrete']) == set(b['discrete'])
+            assert torch.equal(a['discrete']['z_hard'], b['discrete']['z_hard'])
+        else:
+            assert set(a['gaussian']) == set(b['gaussian'])
+            assert torch.equal(a['gaussian']['logvar'], b['gaussian']['logvar'])
+            assert torch.equal(a['gaussian']['mu_mean'], b['gaussian']['mu_mean'])
+    # fp32 training: same kernels, same operands -> identical.  In eval the per-child path returns z = the mu
+    # VIEW, so autograd adds dz to the kernel's d(mu) afterwards (another rounding order); in bf16 the
+    # per-child path sums its narrow-backward contributions in bf16.
+    if dtype == torch.float32 and train:
+        assert torch.equal(g1, g0)
+    elif dtype == torch.float32:
+        close(g1, g0, rtol=1e-6, atol=1e-6)
+    else:
+        close(g1, g0, rtol=2e-2, atol=2e-2)
+
+
+def test_concat_fused_philox_matches_unfused_streams():
+    """Without injected noise both paths draw one (seed, offset) per stochastic child in order, so a
+    re-seeded run of either gives the same sample."""
+    import vae_amd
+    from vae_amd.reparameterizers import ConcatReparameterizer
+    m = ConcatReparameterizer(['isotropic_gaussian', 'discrete'], cfg(continuous_size=64, discrete_size=16))
+    m.train()
+    logits = torch.randn(33, 80, device=DEV)
+    vae_amd.rng.manual_seed(5)
+    z1, _ = m(logits)
+    vae_amd.rng.manual_seed(5)
+    z2, _ = m(logits)
+    z3, _ = m(logits)
+    assert torch.equal(z1, z2) and not torch.equal(z2, z3)
+
+
 class AffineFlow(torch.nn.Module):
     """Stand-in for the host project's flow network (reference flows/ is out of scope)."""
 

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the CDLL below, see module 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VAE_AMD_LIB') or os.path.join(_HERE, 'libvae_amd.so')  # env override: tuning builds only
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 VAE_OK, VAE_ERR_ARG, VAE_ERR_LAUNCH = 0, 1, 2
 VAE_F32, VAE_BF16 = 0, 1
@@ -26,20 +26,22 @@ _p, _i64, _u64, _f, _i = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctype
 SIGNATURES = {
     'vae_abi_version': [],
     'vae_workspace_bytes': [],
-    'vae_gauss_reparam_kl_fwd': [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _f, _f, _i, _u64, _u64, _i64, _i, _p],
-    'vae_gauss_reparam_kl_bwd': [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _f, _f, _i, _u64, _u64, _i64, _i, _p],
+    'vae_gauss_reparam_kl_fwd': [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i64, _i64, _f, _f, _i, _u64, _u64, _i64, _i,
+                                 _p],
+    'vae_gauss_reparam_kl_bwd': [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _f, _f, _i, _u64, _u64, _i64,
+                                 _i, _p],
     'vae_gauss_kl_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i, _p],
     'vae_gauss_kl_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
     'vae_gauss_pair_fwd': [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f, _f, _i,
                            _u64, _u64, _i64, _i, _p],
     'vae_gauss_pair_bwd': [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f, _f,
                            _i, _u64, _u64, _i64, _i, _p],
-    'vae_gumbel_fwd': [_p, _i64, _p, _p, _p, _p, _i64, _i64, _f, _u64, _u64, _i64, _i, _p],
-    'vae_gumbel_bwd': [_p, _p, _p, _p, _p, _p, _i64, _i64, _f, _i, _p],
+    'vae_gumbel_fwd': [_p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _f, _u64, _u64, _i64, _i, _p],
+    'vae_gumbel_bwd': [_p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _f, _i, _p],
     'vae_categorical_kl_fwd': [_p, _i64, _p, _i64, _p, _i64, _i64, _i, _p],
     'vae_categorical_kl_bwd': [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _p],
-    'vae_bernoulli_fwd': [_p, _i64, _p, _p, _p, _i64, _i64, _f, _u64, _u64, _i64, _i, _p],
-    'vae_bernoulli_bwd': [_p, _i64, _p, _p, _p, _p, _i64, _i64, _f, _i, _p],
+    'vae_bernoulli_fwd': [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _f, _u64, _u64, _i64, _i, _p],
+    'vae_bernoulli_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _f, _i, _p],
     'vae_bernoulli_kl_fwd': [_p, _i64, _p, _i64, _p, _i64, _i64, _i, _p],
     'vae_bernoulli_kl_bwd': [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _p],
     'vae_beta_split_kl_fwd': [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _f, _i, _p],

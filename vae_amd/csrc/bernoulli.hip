@@ -31,7 +31,7 @@ __device__ __forceinline__ float sigmoid_div(float v) { return rcp_nr(1.0f + exp
 template <typename T, int V, int U>
 __global__ __launch_bounds__(kBlock) void bernoulli_fwd_kernel(
     const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ unif, T* __restrict__ y_out,
-    T* __restrict__ zh_out, int64_t B, int K, float tau, uint64_t seed, uint64_t offset, int64_t row0, int G,
+    int64_t y_stride, T* __restrict__ zh_out, int64_t zh_stride, int64_t B, int K, float tau, uint64_t seed, uint64_t offset, int64_t row0, int G,
     int64_t tiles) {
   const int rpb = kBlock / G;
   const int sub = threadIdx.x % G;
@@ -61,8 +61,8 @@ __global__ __launch_bounds__(kBlock) void bernoulli_fwd_kernel(
             const float h = y[i] >= 0.5f ? 1.0f : 0.0f;
             zh[i] = add_rn(to_f32(from_f32<T>(sub_rn(h, y[i]))), y[i]);
           }
-          store_vec<T, V>(y_out + row * K + (int64_t)j * V, y);
-          store_vec<T, V>(zh_out + row * K + (int64_t)j * V, zh);
+          store_vec<T, V>(y_out + row * y_stride + (int64_t)j * V, y);
+          store_vec<T, V>(zh_out + row * zh_stride + (int64_t)j * V, zh);
         }
       }
     }
@@ -72,8 +72,9 @@ __global__ __launch_bounds__(kBlock) void bernoulli_fwd_kernel(
 // d y / d l = y (1 - y) / tau wherever sigmoid(l) was not clamped (the clamp passes no gradient)
 template <typename T, int V, int U>
 __global__ __launch_bounds__(kBlock) void bernoulli_bwd_kernel(
-    const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ y, const T* __restrict__ gy,
-    const T* __restrict__ gzh, T* __restrict__ glogits, int64_t B, int K, float tau, int G, int64_t tiles) {
+    const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ y, int64_t y_stride,
+    const T* __restrict__ gy, int64_t gy_stride, const T* __restrict__ gzh, int64_t gzh_stride,
+    T* __restrict__ glogits, int64_t gl_stride, int64_t B, int K, float tau, int G, int64_t tiles) {
   const int rpb = kBlock / G;
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
@@ -86,9 +87,9 @@ __global__ __launch_bounds__(kBlock) void bernoulli_bwd_kernel(
     for (int j0 = sub; j0 < nvec; j0 += G * U) {
       float l[U][V], yv[U][V], g1[U][V], g2[U][V];
       load_chunk<T, V, U>(logits + row * row_stride, j0, G, nvec, l);
-      load_chunk<T, V, U>(y + row * K, j0, G, nvec, yv);
-      if (gy) load_chunk<T, V, U>(gy + row * K, j0, G, nvec, g1);
-      if (gzh) load_chunk<T, V, U>(gzh + row * K, j0, G, nvec, g2);
+      load_chunk<T, V, U>(y + row * y_stride, j0, G, nvec, yv);
+      if (gy) load_chunk<T, V, U>(gy + row * gy_stride, j0, G, nvec, g1);
+      if (gzh) load_chunk<T, V, U>(gzh + row * gzh_stride, j0, G, nvec, g2);
 #pragma unroll
       for (int k = 0; k < U; ++k) {
         const int j = j0 + k * G;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void bernoulli_bwd_kernel(
             const float g = (gy ? g1[k][i] : 0.f) + (gzh ? g2[k][i] : 0.f);
             o[i] = pass * g * yv[k][i] * (1.0f - yv[k][i]) * itau;
           }
-          store_vec<T, V>(glogits + row * K + (int64_t)j * V, o);
+          store_vec<T, V>(glogits + row * gl_stride + (int64_t)j * V, o);
         }
       }
     }
@@ -169,26 +170,28 @@ __global__ __launch_bounds__(kBlock) void bernoulli_kl_kernel(
   }
 
 template <typename T>
-static int bern_fwd_dispatch(const void* logits, int64_t rs, const void* unif, void* y, void* zh, int64_t B,
+static int bern_fwd_dispatch(const void* logits, int64_t rs, const void* unif, void* y, int64_t ys, void* zh,
+                             int64_t zs, int64_t B,
                              int64_t K, float tau, uint64_t seed, uint64_t offset, int64_t row0, hipStream_t stream) {
   constexpr int VN = VecOf<T>::n;
-  const bool vec = (K % VN == 0) && (rs % VN == 0) && aligned16(logits) && aligned16(y) && aligned16(zh) &&
-                   (!unif || aligned16(unif));
+  const bool vec = (K % VN == 0) && (rs % VN == 0) && (ys % VN == 0) && (zs % VN == 0) && aligned16(logits) &&
+                   aligned16(y) && aligned16(zh) && (!unif || aligned16(unif));
   const RowGeom g = row_geom(B, vec ? K / VN : K, kGridStream);
-  BERN_LAUNCH(bernoulli_fwd_kernel, vec, g, (const T*)logits, rs, (const T*)unif, (T*)y, (T*)zh, B, (int)K, tau, seed,
+  BERN_LAUNCH(bernoulli_fwd_kernel, vec, g, (const T*)logits, rs, (const T*)unif, (T*)y, ys, (T*)zh, zs, B, (int)K, tau, seed,
               offset, row0, g.G, g.tiles);
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 
 template <typename T>
-static int bern_bwd_dispatch(const void* logits, int64_t rs, const void* y, const void* gy, const void* gzh,
-                             void* glogits, int64_t B, int64_t K, float tau, hipStream_t stream) {
+static int bern_bwd_dispatch(const void* logits, int64_t rs, const void* y, int64_t ys, const void* gy, int64_t gys,
+                             const void* gzh, int64_t gzs, void* glogits, int64_t gls, int64_t B, int64_t K, float tau, hipStream_t stream) {
   constexpr int VN = VecOf<T>::n;
-  const bool vec = (K % VN == 0) && (rs % VN == 0) && aligned16(logits) && aligned16(y) && aligned16(glogits) &&
+  const bool vec = (K % VN == 0) && (rs % VN == 0) && (ys % VN == 0) && (gys % VN == 0) && (gzs % VN == 0) &&
+                   (gls % VN == 0) && aligned16(logits) && aligned16(y) && aligned16(glogits) &&
                    (!gy || aligned16(gy)) && (!gzh || aligned16(gzh));
   const RowGeom g = row_geom(B, vec ? K / VN : K, kGridStream);
-  BERN_LAUNCH(bernoulli_bwd_kernel, vec, g, (const T*)logits, rs, (const T*)y, (const T*)gy, (const T*)gzh,
-              (T*)glogits, B, (int)K, tau, g.G, g.tiles);
+  BERN_LAUNCH(bernoulli_bwd_kernel, vec, g, (const T*)logits, rs, (const T*)y, ys, (const T*)gy, gys, (const T*)gzh, gzs,
+              (T*)glogits, gls, B, (int)K, tau, g.G, g.tiles);
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 
@@ -217,26 +220,38 @@ using namespace vae;
 
 extern "C" {
 
-int vae_bernoulli_fwd(const void* logits, int64_t row_stride, const void* unif, void* y, void* z_hard, int64_t B,
+int vae_bernoulli_fwd(const void* logits, int64_t row_stride, const void* unif, void* y, int64_t y_stride, void* z_hard,
+                      int64_t z_hard_stride, int64_t B,
                       int64_t K, float tau, uint64_t seed, uint64_t offset, int64_t row0, int dtype,
                       vae_stream_t stream) {
   if (B < 0 || K <= 0 || K > VAE_MAX_ROW || !(tau > 0.f)) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
-  if (!logits || !y || !z_hard || row_stride < K) return VAE_ERR_ARG;
+  if (y_stride == 0) y_stride = K;
+  if (z_hard_stride == 0) z_hard_stride = K;
+  if (!logits || !y || !z_hard || row_stride < K || y_stride < K || z_hard_stride < K) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == VAE_F32) return bern_fwd_dispatch<float>(logits, row_stride, unif, y, z_hard, B, K, tau, seed, offset, row0, st);
-  if (dtype == VAE_BF16) return bern_fwd_dispatch<bf16_t>(logits, row_stride, unif, y, z_hard, B, K, tau, seed, offset, row0, st);
+  if (dtype == VAE_F32) return bern_fwd_dispatch<float>(logits, row_stride, unif, y, y_stride, z_hard, z_hard_stride, B, K, tau, seed, offset, row0, st);
+  if (dtype == VAE_BF16) return bern_fwd_dispatch<bf16_t>(logits, row_stride, unif, y, y_stride, z_hard, z_hard_stride, B, K, tau, seed, offset, row0, st);
   return VAE_ERR_ARG;
 }
 
-int vae_bernoulli_bwd(const void* logits, int64_t row_stride, const void* y, const void* gy, const void* gz_hard,
-                      void* glogits, int64_t B, int64_t K, float tau, int dtype, vae_stream_t stream) {
+int vae_bernoulli_bwd(const void* logits, int64_t row_stride, const void* y, int64_t y_stride, const void* gy,
+                      int64_t gy_stride, const void* gz_hard, int64_t gz_hard_stride, void* glogits,
+                      int64_t glogits_stride, int64_t B, int64_t K, float tau, int dtype, vae_stream_t stream) {
   if (B < 0 || K <= 0 || K > VAE_MAX_ROW || !(tau > 0.f)) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
-  if (!logits || !y || !glogits || row_stride < K) return VAE_ERR_ARG;
+  if (y_stride == 0) y_stride = K;
+  if (gy_stride == 0) gy_stride = K;
+  if (gz_hard_stride == 0) gz_hard_stride = K;
+  if (glogits_stride == 0) glogits_stride = K;
+  if (!logits || !y || !glogits || row_stride < K || y_stride < K || gy_stride < K || gz_hard_stride < K ||
+      glogits_stride < K)
+    return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == VAE_F32) return bern_bwd_dispatch<float>(logits, row_stride, y, gy, gz_hard, glogits, B, K, tau, st);
-  if (dtype == VAE_BF16) return bern_bwd_dispatch<bf16_t>(logits, row_stride, y, gy, gz_hard, glogits, B, K, tau, st);
+  if (dtype == VAE_F32) return bern_bwd_dispatch<float>(logits, row_stride, y, y_stride, gy, gy_stride, gz_hard,
+                                                         gz_hard_stride, glogits, glogits_stride, B, K, tau, st);
+  if (dtype == VAE_BF16) return bern_bwd_dispatch<bf16_t>(logits, row_stride, y, y_stride, gy, gy_stride, gz_hard,
+                                                           gz_hard_stride, glogits, glogits_stride, B, K, tau, st);
   return VAE_ERR_ARG;
 }
 

@@ -30,7 +30,7 @@ constexpr bool kNtGaussFwd = VAE_NT_GAUSS_FWD != 0, kNtGaussBwd = VAE_NT_GAUSS_B
 template <typename T, int V, int U>
 __global__ __launch_bounds__(kBlock) void gauss_fwd_kernel(
     const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ noise, T* __restrict__ z,
-    T* __restrict__ s_out, T* __restrict__ kl, float* __restrict__ ws, float mean_scale,
+    int64_t z_stride, T* __restrict__ s_out, T* __restrict__ kl, float* __restrict__ ws, float mean_scale,
     float* __restrict__ means, int64_t B, int L, float eps_tol, int training, uint64_t seed, uint64_t offset, int64_t row0, int G, int64_t tiles) {
   const int rpb = kBlock / G;
   const int sub = threadIdx.x % G;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kBlock) void gauss_fwd_kernel(
               acc[0] += m;
               acc[1] += si;
             }
-            if (z) store_vec<T, V>(z + row * L + (int64_t)j * V, zz);
+            if (z) store_vec<T, V>(z + row * z_stride + (int64_t)j * V, zz);
             if (s_out) store_vec<T, V>(s_out + row * L + (int64_t)j * V, s[u]);
           }
         }
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(kBlock) void gauss_fwd_kernel(
 template <typename T, int V, int U>
 __global__ __launch_bounds__(kBlock) void gauss_bwd_kernel(
     const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ noise, const T* __restrict__ gz,
-    const T* __restrict__ gs, const T* __restrict__ gkl, const float* __restrict__ gmeans, T* __restrict__ glogits,
-    int64_t B, int L, float eps_tol, float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0,
+    int64_t gz_stride, const T* __restrict__ gs, const T* __restrict__ gkl, const float* __restrict__ gmeans,
+    T* __restrict__ glogits, int64_t gl_stride, int64_t B, int L, float eps_tol, float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0,
     int G, int64_t tiles) {
   const int rpb = kBlock / G;
   const int sub = threadIdx.x % G;
@@ -103,13 +103,13 @@ __global__ __launch_bounds__(kBlock) void gauss_bwd_kernel(
     const int64_t row = t * rpb + rloc;
     if (row >= B) continue;
     const T* lrow = logits + row * row_stride;
-    T* grow = glogits + row * 2 * (int64_t)L;
+    T* grow = glogits + row * gl_stride;
     const float gk = gkl ? to_f32(gkl[row]) : 0.f;
     for (int j0 = sub; j0 < nvec; j0 += G * U) {
       float mu[U][V], s[U][V], e[U][V], g[U][V], g2[U][V];
       load_chunk<T, V, U, kNtGaussBwd>(lrow, j0, G, nvec, mu);
       load_chunk<T, V, U, kNtGaussBwd>(lrow + L, j0, G, nvec, s);
-      if (gz) load_chunk<T, V, U, kNtGaussBwd>(gz + row * L, j0, G, nvec, g);
+      if (gz) load_chunk<T, V, U, kNtGaussBwd>(gz + row * gz_stride, j0, G, nvec, g);
       if (gs) load_chunk<T, V, U, kNtGaussBwd>(gs + row * L, j0, G, nvec, g2);
       if (use_e && noise) load_chunk<T, V, U, kNtGaussBwd>(noise + row * L, j0, G, nvec, e);
 #pragma unroll
@@ -233,23 +233,25 @@ __global__ __launch_bounds__(kBlock) void gauss_kl_bwd_kernel(
 }
 
 template <typename T>
-static int gauss_fwd_dispatch(const void* logits, int64_t row_stride, const void* noise, void* z, void* s_out,
+static int gauss_fwd_dispatch(const void* logits, int64_t row_stride, const void* noise, void* z, int64_t z_stride,
+                              void* s_out,
                               void* kl, float* means, float* workspace, int64_t B, int64_t L, float eps_tol,
                               float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0,
                               hipStream_t stream) {
   constexpr int VN = VecOf<T>::n;
-  const bool vec = (L % VN == 0) && (row_stride % VN == 0) && aligned16(logits) && (!z || aligned16(z)) &&
+  const bool vec = (L % VN == 0) && (row_stride % VN == 0) && (z_stride % VN == 0) && aligned16(logits) &&
+                   (!z || aligned16(z)) &&
                    (!noise || aligned16(noise)) && (!s_out || aligned16(s_out));
   const RowGeom g = row_geom(B, vec ? L / VN : L, means ? kGridReduce : kGridStream);
   if (!means) workspace = nullptr;
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gauss_fwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                         (const T*)logits, row_stride, (const T*)noise, (T*)z, (T*)s_out, (T*)kl,
+                                         (const T*)logits, row_stride, (const T*)noise, (T*)z, z_stride, (T*)s_out, (T*)kl,
                                          workspace, mean_scale, means, B, (int)L, eps_tol, training, seed, offset,
                                          row0, g.G, g.tiles));
   } else {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gauss_fwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                         (const T*)logits, row_stride, (const T*)noise, (T*)z, (T*)s_out, (T*)kl,
+                                         (const T*)logits, row_stride, (const T*)noise, (T*)z, z_stride, (T*)s_out, (T*)kl,
                                          workspace, mean_scale, means, B, (int)L, eps_tol, training, seed, offset,
                                          row0, g.G, g.tiles));
   }
@@ -258,22 +260,24 @@ static int gauss_fwd_dispatch(const void* logits, int64_t row_stride, const void
 
 template <typename T>
 static int gauss_bwd_dispatch(const void* logits, int64_t row_stride, const void* noise, const void* gz,
-                              const void* gs, const void* gkl, const float* gmeans, void* glogits, int64_t B,
+                              int64_t gz_stride, const void* gs, const void* gkl, const float* gmeans, void* glogits,
+                              int64_t gl_stride, int64_t B,
                               int64_t L, float eps_tol, float mean_scale, int training, uint64_t seed,
                               uint64_t offset, int64_t row0, hipStream_t stream) {
   constexpr int VN = VecOf<T>::n;
-  const bool vec = (L % VN == 0) && (row_stride % VN == 0) && aligned16(logits) && aligned16(glogits) &&
+  const bool vec = (L % VN == 0) && (row_stride % VN == 0) && (gz_stride % VN == 0) && (gl_stride % VN == 0) &&
+                   aligned16(logits) && aligned16(glogits) &&
                    (!noise || aligned16(noise)) && (!gz || aligned16(gz)) && (!gs || aligned16(gs));
   const RowGeom g = row_geom(B, vec ? L / VN : L, kGridStream);
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gauss_bwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                         (const T*)logits, row_stride, (const T*)noise, (const T*)gz, (const T*)gs,
-                                         (const T*)gkl, gmeans, (T*)glogits, B, (int)L, eps_tol, mean_scale, training,
+                                         (const T*)logits, row_stride, (const T*)noise, (const T*)gz, gz_stride,
+                                         (const T*)gs, (const T*)gkl, gmeans, (T*)glogits, gl_stride, B, (int)L, eps_tol, mean_scale, training,
                                          seed, offset, row0, g.G, g.tiles));
   } else {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gauss_bwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                         (const T*)logits, row_stride, (const T*)noise, (const T*)gz, (const T*)gs,
-                                         (const T*)gkl, gmeans, (T*)glogits, B, (int)L, eps_tol, mean_scale, training,
+                                         (const T*)logits, row_stride, (const T*)noise, (const T*)gz, gz_stride,
+                                         (const T*)gs, (const T*)gkl, gmeans, (T*)glogits, gl_stride, B, (int)L, eps_tol, mean_scale, training,
                                          seed, offset, row0, g.G, g.tiles));
   }
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
@@ -327,36 +331,42 @@ using namespace vae;
 
 extern "C" {
 
-int vae_gauss_reparam_kl_fwd(const void* logits, int64_t row_stride, const void* noise, void* z, void* s_out,
+int vae_gauss_reparam_kl_fwd(const void* logits, int64_t row_stride, const void* noise, void* z, int64_t z_stride,
+                             void* s_out,
                              void* kl, float* means, float* workspace, int64_t B, int64_t L, float eps_tol,
                              float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0, int dtype,
                              vae_stream_t stream) {
   if (B < 0 || L <= 0 || L > VAE_MAX_ROW) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
-  if (!logits || (!z && training) || !kl || !workspace || row_stride < 2 * L) return VAE_ERR_ARG;
+  if (z_stride == 0) z_stride = L;
+  if (!logits || (!z && training) || !kl || !workspace || row_stride < 2 * L || z_stride < L) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32)
-    return gauss_fwd_dispatch<float>(logits, row_stride, noise, z, s_out, kl, means, workspace, B, L, eps_tol,
+    return gauss_fwd_dispatch<float>(logits, row_stride, noise, z, z_stride, s_out, kl, means, workspace, B, L, eps_tol,
                                      mean_scale, training, seed, offset, row0, st);
   if (dtype == VAE_BF16)
-    return gauss_fwd_dispatch<bf16_t>(logits, row_stride, noise, z, s_out, kl, means, workspace, B, L, eps_tol,
+    return gauss_fwd_dispatch<bf16_t>(logits, row_stride, noise, z, z_stride, s_out, kl, means, workspace, B, L, eps_tol,
                                       mean_scale, training, seed, offset, row0, st);
   return VAE_ERR_ARG;
 }
 
 int vae_gauss_reparam_kl_bwd(const void* logits, int64_t row_stride, const void* noise, const void* gz,
-                             const void* gs, const void* gkl, const float* gmeans, void* glogits, int64_t B,
+                             int64_t gz_stride, const void* gs, const void* gkl, const float* gmeans, void* glogits,
+                             int64_t glogits_stride, int64_t B,
                              int64_t L, float eps_tol, float mean_scale, int training, uint64_t seed,
                              uint64_t offset, int64_t row0, int dtype, vae_stream_t stream) {
   if (B < 0 || L <= 0 || L > VAE_MAX_ROW) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
-  if (!logits || !glogits || row_stride < 2 * L) return VAE_ERR_ARG;
+  if (gz_stride == 0) gz_stride = L;
+  if (glogits_stride == 0) glogits_stride = 2 * L;
+  if (!logits || !glogits || row_stride < 2 * L || gz_stride < L || glogits_stride < 2 * L) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32)
-    return gauss_bwd_dispatch<float>(logits, row_stride, noise, gz, gs, gkl, gmeans, glogits, B, L, eps_tol,
+    return gauss_bwd_dispatch<float>(logits, row_stride, noise, gz, gz_stride, gs, gkl, gmeans, glogits, glogits_stride, B, L, eps_tol,
                                      mean_scale, training, seed, offset, row0, st);
   if (dtype == VAE_BF16)
-    return gauss_bwd_dispatch<bf16_t>(logits, row_stride, noise, gz, gs, gkl, gmeans, glogits, B, L, eps_tol,
+    return gauss_bwd_dispatch<bf16_t>(logits, row_stride, noise, gz, gz_stride, gs, gkl, gmeans, glogits, glogits_stride,
+                                      B, L, eps_tol,
                                       mean_scale, training, seed, offset, row0, st);
   return VAE_ERR_ARG;
 }

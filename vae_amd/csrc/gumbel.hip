@@ -26,7 +26,7 @@ constexpr float kNegInf = -3.402823466e+38f;
 template <typename T, int V, int U>
 __global__ __launch_bounds__(kBlock) void gumbel_fwd_kernel(
     const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ unif, T* __restrict__ y_out,
-    T* __restrict__ zh_out, T* __restrict__ lq_out, int64_t B, int K, float tau, uint64_t seed, uint64_t offset,
+    int64_t y_stride, T* __restrict__ zh_out, int64_t zh_stride, T* __restrict__ lq_out, int64_t B, int K, float tau, uint64_t seed, uint64_t offset,
     int64_t row0, int G, int64_t tiles) {
   const int rpb = kBlock / G;
   const int sub = threadIdx.x % G;
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(kBlock) void gumbel_fwd_kernel(
             zh[i] = add_rn(to_f32(from_f32<T>(sub_rn(h, x[k][i]))), x[k][i]);  // (h - y).detach() + y
             lq[i] = sub_rn(sub_rn(l[k][i], m1), lse);
           }
-          store_vec<T, V>(y_out + row * K + (int64_t)j * V, x[k]);
-          store_vec<T, V>(zh_out + row * K + (int64_t)j * V, zh);
+          store_vec<T, V>(y_out + row * y_stride + (int64_t)j * V, x[k]);
+          store_vec<T, V>(zh_out + row * zh_stride + (int64_t)j * V, zh);
           store_vec<T, V>(lq_out + row * K + (int64_t)j * V, lq);
         }
       }
@@ -127,8 +127,9 @@ __global__ __launch_bounds__(kBlock) void gumbel_fwd_kernel(
 // ---------------------------------------------------------------------------
 template <typename T, int V, int U>
 __global__ __launch_bounds__(kBlock) void gumbel_bwd_kernel(
-    const T* __restrict__ y, const T* __restrict__ lq, const T* __restrict__ gy, const T* __restrict__ gzh,
-    const T* __restrict__ glq, T* __restrict__ glogits, int64_t B, int K, float tau, int G, int64_t tiles) {
+    const T* __restrict__ y, int64_t y_stride, const T* __restrict__ lq, const T* __restrict__ gy, int64_t gy_stride,
+    const T* __restrict__ gzh, int64_t gzh_stride, const T* __restrict__ glq, T* __restrict__ glogits,
+    int64_t gl_stride, int64_t B, int K, float tau, int G, int64_t tiles) {
   const int rpb = kBlock / G;
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
@@ -141,9 +142,9 @@ __global__ __launch_bounds__(kBlock) void gumbel_bwd_kernel(
     const int64_t r = live ? row : B - 1;
     float yv[U][V], gt[U][V], q[U][V], gq[U][V];
     const bool soft = gy || gzh;
-    if (soft) load_chunk<T, V, U>(y + r * K, sub, G, nvec, yv);
-    if (gy) load_chunk<T, V, U>(gy + r * K, sub, G, nvec, gt);
-    if (gzh) load_chunk<T, V, U>(gzh + r * K, sub, G, nvec, q);
+    if (soft) load_chunk<T, V, U>(y + r * y_stride, sub, G, nvec, yv);
+    if (gy) load_chunk<T, V, U>(gy + r * gy_stride, sub, G, nvec, gt);
+    if (gzh) load_chunk<T, V, U>(gzh + r * gzh_stride, sub, G, nvec, q);
     if (gy && gzh) {
 #pragma unroll
       for (int k = 0; k < U; ++k)
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void gumbel_bwd_kernel(
             if (glq) v += gq[k][i] - expf(q[k][i]) * sg;
             o[i] = v;
           }
-          store_vec<T, V>(glogits + row * K + (int64_t)j * V, o);
+          store_vec<T, V>(glogits + row * gl_stride + (int64_t)j * V, o);
         }
       }
     }
@@ -267,42 +268,45 @@ __global__ __launch_bounds__(kBlock) void categorical_kl_kernel(
 }
 
 template <typename T>
-static int gumbel_fwd_dispatch(const void* logits, int64_t row_stride, const void* unif, void* y, void* zh, void* lq,
+static int gumbel_fwd_dispatch(const void* logits, int64_t row_stride, const void* unif, void* y, int64_t ys, void* zh,
+                               int64_t zs, void* lq,
                                int64_t B, int64_t K, float tau, uint64_t seed, uint64_t offset, int64_t row0,
                                hipStream_t stream) {
   constexpr int VN = VecOf<T>::n;
-  const bool vec = (K % VN == 0) && (row_stride % VN == 0) && aligned16(logits) && aligned16(y) && aligned16(zh) &&
+  const bool vec = (K % VN == 0) && (row_stride % VN == 0) && (ys % VN == 0) && (zs % VN == 0) && aligned16(logits) &&
+                   aligned16(y) && aligned16(zh) &&
                    aligned16(lq) && (!unif || aligned16(unif));
   RowGeom g;
   if (!row_geom_resident(B, vec ? K / VN : K, kGridStream, &g)) return VAE_ERR_ARG;
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gumbel_fwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                         (const T*)logits, row_stride, (const T*)unif, (T*)y, (T*)zh, (T*)lq, B,
+                                         (const T*)logits, row_stride, (const T*)unif, (T*)y, ys, (T*)zh, zs, (T*)lq, B,
                                          (int)K, tau, seed, offset, row0, g.G, g.tiles));
   } else {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gumbel_fwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                         (const T*)logits, row_stride, (const T*)unif, (T*)y, (T*)zh, (T*)lq, B,
+                                         (const T*)logits, row_stride, (const T*)unif, (T*)y, ys, (T*)zh, zs, (T*)lq, B,
                                          (int)K, tau, seed, offset, row0, g.G, g.tiles));
   }
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 
 template <typename T>
-static int gumbel_bwd_dispatch(const void* y, const void* lq, const void* gy, const void* gzh, const void* glq,
-                               void* glogits, int64_t B, int64_t K, float tau, hipStream_t stream) {
+static int gumbel_bwd_dispatch(const void* y, int64_t ys, const void* lq, const void* gy, int64_t gys, const void* gzh,
+                               int64_t gzs, const void* glq, void* glogits, int64_t gls, int64_t B, int64_t K, float tau, hipStream_t stream) {
   constexpr int VN = VecOf<T>::n;
-  const bool vec = (K % VN == 0) && aligned16(y) && aligned16(lq) && aligned16(glogits) && (!gy || aligned16(gy)) &&
+  const bool vec = (K % VN == 0) && (ys % VN == 0) && (gys % VN == 0) && (gzs % VN == 0) && (gls % VN == 0) &&
+                   aligned16(y) && aligned16(lq) && aligned16(glogits) && (!gy || aligned16(gy)) &&
                    (!gzh || aligned16(gzh)) && (!glq || aligned16(glq));
   RowGeom g;
   if (!row_geom_resident(B, vec ? K / VN : K, kGridStream, &g)) return VAE_ERR_ARG;
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gumbel_bwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                         (const T*)y, (const T*)lq, (const T*)gy, (const T*)gzh, (const T*)glq,
-                                         (T*)glogits, B, (int)K, tau, g.G, g.tiles));
+                                         (const T*)y, ys, (const T*)lq, (const T*)gy, gys, (const T*)gzh, gzs,
+                                         (const T*)glq, (T*)glogits, gls, B, (int)K, tau, g.G, g.tiles));
   } else {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gumbel_bwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                         (const T*)y, (const T*)lq, (const T*)gy, (const T*)gzh, (const T*)glq,
-                                         (T*)glogits, B, (int)K, tau, g.G, g.tiles));
+                                         (const T*)y, ys, (const T*)lq, (const T*)gy, gys, (const T*)gzh, gzs,
+                                         (const T*)glq, (T*)glogits, gls, B, (int)K, tau, g.G, g.tiles));
   }
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
@@ -333,29 +337,40 @@ using namespace vae;
 
 extern "C" {
 
-int vae_gumbel_fwd(const void* logits, int64_t row_stride, const void* unif, void* y, void* z_hard, void* log_q_z,
+int vae_gumbel_fwd(const void* logits, int64_t row_stride, const void* unif, void* y, int64_t y_stride, void* z_hard,
+                   int64_t z_hard_stride, void* log_q_z,
                    int64_t B, int64_t K, float tau, uint64_t seed, uint64_t offset, int64_t row0, int dtype,
                    vae_stream_t stream) {
   if (B < 0 || K <= 0 || K > VAE_MAX_SOFTMAX_ROW || !(tau > 0.f)) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
-  if (!logits || !y || !z_hard || !log_q_z || row_stride < K) return VAE_ERR_ARG;
+  if (y_stride == 0) y_stride = K;
+  if (z_hard_stride == 0) z_hard_stride = K;
+  if (!logits || !y || !z_hard || !log_q_z || row_stride < K || y_stride < K || z_hard_stride < K) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32)
-    return gumbel_fwd_dispatch<float>(logits, row_stride, unif, y, z_hard, log_q_z, B, K, tau, seed, offset, row0, st);
+    return gumbel_fwd_dispatch<float>(logits, row_stride, unif, y, y_stride, z_hard, z_hard_stride, log_q_z, B, K, tau, seed, offset, row0, st);
   if (dtype == VAE_BF16)
-    return gumbel_fwd_dispatch<bf16_t>(logits, row_stride, unif, y, z_hard, log_q_z, B, K, tau, seed, offset, row0,
+    return gumbel_fwd_dispatch<bf16_t>(logits, row_stride, unif, y, y_stride, z_hard, z_hard_stride, log_q_z, B, K, tau, seed, offset, row0,
                                        st);
   return VAE_ERR_ARG;
 }
 
-int vae_gumbel_bwd(const void* y, const void* log_q_z, const void* gy, const void* gz_hard, const void* glog_q_z,
-                   void* glogits, int64_t B, int64_t K, float tau, int dtype, vae_stream_t stream) {
+int vae_gumbel_bwd(const void* y, int64_t y_stride, const void* log_q_z, const void* gy, int64_t gy_stride,
+                   const void* gz_hard, int64_t gz_hard_stride, const void* glog_q_z, void* glogits,
+                   int64_t glogits_stride, int64_t B, int64_t K, float tau, int dtype, vae_stream_t stream) {
   if (B < 0 || K <= 0 || K > VAE_MAX_SOFTMAX_ROW || !(tau > 0.f)) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
-  if (!y || !log_q_z || !glogits) return VAE_ERR_ARG;
+  if (y_stride == 0) y_stride = K;
+  if (gy_stride == 0) gy_stride = K;
+  if (gz_hard_stride == 0) gz_hard_stride = K;
+  if (glogits_stride == 0) glogits_stride = K;
+  if (!y || !log_q_z || !glogits || y_stride < K || gy_stride < K || gz_hard_stride < K || glogits_stride < K)
+    return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == VAE_F32) return gumbel_bwd_dispatch<float>(y, log_q_z, gy, gz_hard, glog_q_z, glogits, B, K, tau, st);
-  if (dtype == VAE_BF16) return gumbel_bwd_dispatch<bf16_t>(y, log_q_z, gy, gz_hard, glog_q_z, glogits, B, K, tau, st);
+  if (dtype == VAE_F32) return gumbel_bwd_dispatch<float>(y, y_stride, log_q_z, gy, gy_stride, gz_hard, gz_hard_stride, glog_q_z, glogits,
+                                      glogits_stride, B, K, tau, st);
+  if (dtype == VAE_BF16) return gumbel_bwd_dispatch<bf16_t>(y, y_stride, log_q_z, gy, gy_stride, gz_hard, gz_hard_stride, glog_q_z, glogits,
+                                       glogits_stride, B, K, tau, st);
   return VAE_ERR_ARG;
 }
 

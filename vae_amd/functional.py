@@ -57,7 +57,7 @@ class _GaussReparamKL(torch.autograd.Function):
         if mean_scale is None:
             mean_scale = 1.0 / max(B * L, 1)
         with _Guard(dev):
-            call('vae_gauss_reparam_kl_fwd', ptr(logits), logits.stride(0), ptr(noise), ptr(z), ptr(logvar), ptr(kl),
+            call('vae_gauss_reparam_kl_fwd', ptr(logits), logits.stride(0), ptr(noise), ptr(z), 0, ptr(logvar), ptr(kl),
                  ptr(means), ptr(workspace(dev)), B, L, eps_tol, mean_scale, int(training), seed & _MASK64,
                  offset & _MASK64, row0, dtype_code(logits), stream_ptr(dev))
         ctx.save_for_backward(logits, noise)
@@ -79,8 +79,8 @@ class _GaussReparamKL(torch.autograd.Function):
         gmeans = None if gmeans is None else gmeans.contiguous().float()
         glogits = torch.empty((B, 2 * L), dtype=logits.dtype, device=dev)
         with _Guard(dev):
-            call('vae_gauss_reparam_kl_bwd', ptr(logits), logits.stride(0), ptr(noise), ptr(gz), ptr(glogvar),
-                 ptr(gkl), ptr(gmeans), ptr(glogits), B, L, eps_tol, mean_scale, int(training), seed & _MASK64,
+            call('vae_gauss_reparam_kl_bwd', ptr(logits), logits.stride(0), ptr(noise), ptr(gz), 0, ptr(glogvar),
+                 ptr(gkl), ptr(gmeans), ptr(glogits), 0, B, L, eps_tol, mean_scale, int(training), seed & _MASK64,
                  offset & _MASK64, row0, dtype_code(logits), stream_ptr(dev))
         return glogits, None, None, None, None, None, None, None
 
@@ -277,7 +277,7 @@ class _Gumbel(torch.autograd.Function):
         zh = torch.empty_like(y)
         lq = torch.empty_like(y)
         with _Guard(dev):
-            call('vae_gumbel_fwd', ptr(logits), logits.stride(0), ptr(unif), ptr(y), ptr(zh), ptr(lq), B, K, tau,
+            call('vae_gumbel_fwd', ptr(logits), logits.stride(0), ptr(unif), ptr(y), 0, ptr(zh), 0, ptr(lq), B, K, tau,
                  seed & _MASK64, offset & _MASK64, row0, dtype_code(logits), stream_ptr(dev))
         ctx.save_for_backward(y, lq)
         ctx.tau = tau
@@ -293,7 +293,7 @@ class _Gumbel(torch.autograd.Function):
         gy, gzh, glq = _dense(gy), _dense(gzh), _dense(glq)
         gl = torch.empty_like(y)
         with _Guard(dev):
-            call('vae_gumbel_bwd', ptr(y), ptr(lq), ptr(gy), ptr(gzh), ptr(glq), ptr(gl), B, K, ctx.tau,
+            call('vae_gumbel_bwd', ptr(y), 0, ptr(lq), ptr(gy), 0, ptr(gzh), 0, ptr(glq), ptr(gl), 0, B, K, ctx.tau,
                  dtype_code(y), stream_ptr(dev))
         return gl, None, None, None, None, None
 
@@ -357,7 +357,7 @@ class _Bernoulli(torch.autograd.Function):
         y = torch.empty((B, K), dtype=logits.dtype, device=dev)
         zh = torch.empty_like(y)
         with _Guard(dev):
-            call('vae_bernoulli_fwd', ptr(logits), logits.stride(0), ptr(unif), ptr(y), ptr(zh), B, K, tau,
+            call('vae_bernoulli_fwd', ptr(logits), logits.stride(0), ptr(unif), ptr(y), 0, ptr(zh), 0, B, K, tau,
                  seed & _MASK64, offset & _MASK64, row0, dtype_code(logits), stream_ptr(dev))
         ctx.save_for_backward(logits, y)
         ctx.tau = tau
@@ -372,8 +372,8 @@ class _Bernoulli(torch.autograd.Function):
         B, K = y.shape
         gl = torch.empty_like(y)
         with _Guard(dev):
-            call('vae_bernoulli_bwd', ptr(logits), logits.stride(0), ptr(y), ptr(_dense(gy)), ptr(_dense(gzh)),
-                 ptr(gl), B, K, ctx.tau, dtype_code(y), stream_ptr(dev))
+            call('vae_bernoulli_bwd', ptr(logits), logits.stride(0), ptr(y), 0, ptr(_dense(gy)), 0, ptr(_dense(gzh)), 0,
+                 ptr(gl), 0, B, K, ctx.tau, dtype_code(y), stream_ptr(dev))
         return gl, None, None, None, None, None
 
 
@@ -639,3 +639,129 @@ def gauss_pair(enc_logits, prior_logits, noise_post=None, noise_prior=None, eps_
     z_q, z_p, lv_q, lv_p, clamped, kl_pair, kl_prior, means = out
     return ((z_q if training else None), (z_p if training else None), lv_q, lv_p, clamped, kl_pair,
             (kl_prior if with_prior_kl else None), means)
+
+
+# --------------------------------------------------------------------------------------
+# ConcatReparameterizer over kernel-backed leaves: children read strided slices of the shared
+# logits buffer, write their samples straight into the concatenated output and their gradients
+# straight into ONE d(logits) buffer -- no torch.cat, no narrow-backward zero-fills and adds.
+# --------------------------------------------------------------------------------------
+def _poff(t, elems):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr() + elems * t.element_size())
+
+
+class _ConcatLeaves(torch.autograd.Function):
+    """specs: tuple of ('gauss', L, eps_tol, mean_scale) | ('gumbel', K, tau) | ('bern', K, tau);
+    noises / seeds: one entry per child (tensor or None; (seed, offset))."""
+
+    @staticmethod
+    def forward(ctx, logits, specs, training, noises, seeds, row0):
+        ctx.set_materialize_grads(False)
+        dev = check_device(logits, *[n for n in noises if n is not None])
+        B, W_in = logits.shape
+        rs = logits.stride(0)
+        W_out = sum(s[1] for s in specs)
+        dt = dtype_code(logits)
+        new = lambda *s: torch.empty(s, dtype=logits.dtype, device=dev)
+        zcat = new(B, W_out)
+        outs, saved = [zcat], []
+        i_off = o_off = 0
+        st = stream_ptr(dev)
+        with _Guard(dev):
+            for spec, noise, (seed, offset) in zip(specs, noises, seeds):
+                kind, n = spec[0], spec[1]
+                if kind == 'gauss':
+                    _, L, eps_tol, mean_scale = spec
+                    logvar, kl = new(B, L), new(B)
+                    means = torch.zeros((2,), dtype=torch.float32, device=dev)
+                    ms = 1.0 / max(B * L, 1) if mean_scale is None else mean_scale
+                    call('vae_gauss_reparam_kl_fwd', _poff(logits, i_off), rs, ptr(noise), _poff(zcat, o_off), W_out,
+                         ptr(logvar), ptr(kl), ptr(means), ptr(workspace(dev)), B, L, eps_tol, ms, int(training),
+                         seed & _MASK64, offset & _MASK64, row0, dt, st)
+                    outs += [logvar, kl, means]
+                    i_off, o_off = i_off + 2 * L, o_off + L
+                else:
+                    K, tau = spec[1], spec[2]
+                    other = new(B, K)          # the output that does NOT go into the concatenated sample
+                    y_ptr, y_s, zh_ptr, zh_s = (_poff(zcat, o_off), W_out, ptr(other), K) if training else \
+                        (ptr(other), K, _poff(zcat, o_off), W_out)
+                    if kind == 'gumbel':
+                        lq = new(B, K)
+                        call('vae_gumbel_fwd', _poff(logits, i_off), rs, ptr(noise), y_ptr, y_s, zh_ptr, zh_s, ptr(lq),
+                             B, K, tau, seed & _MASK64, offset & _MASK64, row0, dt, st)
+                        outs += [other, lq]
+                    else:
+                        call('vae_bernoulli_fwd', _poff(logits, i_off), rs, ptr(noise), y_ptr, y_s, zh_ptr, zh_s, B, K,
+                             tau, seed & _MASK64, offset & _MASK64, row0, dt, st)
+                        outs += [other]
+                    i_off, o_off = i_off + K, o_off + K
+        ctx.specs, ctx.training, ctx.seeds, ctx.row0 = specs, training, seeds, row0
+        ctx.n_noise = len(noises)
+        ctx.save_for_backward(logits, *noises, *outs)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, gzcat, *gex):
+        specs, training = ctx.specs, ctx.training
+        sv = ctx.saved_tensors
+        logits, noises, outs = sv[0], sv[1:1 + ctx.n_noise], sv[1 + ctx.n_noise:]
+        zcat = outs[0]
+        dev = logits.device
+        B, W_in = logits.shape
+        rs = logits.stride(0)
+        W_out = zcat.shape[1]
+        dt = dtype_code(logits)
+        gzcat = _dense(gzcat)
+        glogits = torch.empty((B, W_in), dtype=logits.dtype, device=dev)
+        i_off = o_off = 0
+        k = 0          # index into outs[1:] / gex
+        st = stream_ptr(dev)
+        gslice = lambda off: (None, 0) if gzcat is None else (_poff(gzcat, off), W_out)
+        with _Guard(dev):
+            for spec, noise, (seed, offset) in zip(specs, noises, ctx.seeds):
+                kind = spec[0]
+                if kind == 'gauss':
+                    _, L, eps_tol, mean_scale = spec
+                    glv, gkl, gm = _dense(gex[k]), _dense(gex[k + 1]), gex[k + 2]
+                    gm = None if gm is None else gm.contiguous().float()
+                    ms = 1.0 / max(B * L, 1) if mean_scale is None else mean_scale
+                    gz_p, gz_s = gslice(o_off)
+                    call('vae_gauss_reparam_kl_bwd', _poff(logits, i_off), rs, ptr(noise), gz_p, gz_s, ptr(glv),
+                         ptr(gkl), ptr(gm), _poff(glogits, i_off), W_in, B, L, eps_tol, ms, int(training),
+                         seed & _MASK64, offset & _MASK64, ctx.row0, dt, st)
+                    k += 3
+                    i_off, o_off = i_off + 2 * L, o_off + L
+                else:
+                    K, tau = spec[1], spec[2]
+                    other, g_other = outs[1 + k], _dense(gex[k])
+                    gc_p, gc_s = gslice(o_off)
+                    if training:   # y lives in zcat, z_hard is `other`
+                        y_p, y_s, gy_p, gy_s, gzh_p, gzh_s = _poff(zcat, o_off), W_out, gc_p, gc_s, ptr(g_other), K
+                    else:          # z_hard lives in zcat, y is `other`
+                        y_p, y_s, gy_p, gy_s, gzh_p, gzh_s = ptr(other), K, ptr(g_other), K, gc_p, gc_s
+                    if kind == 'gumbel':
+                        lq, glq = outs[2 + k], _dense(gex[k + 1])
+                        call('vae_gumbel_bwd', y_p, y_s, ptr(lq), gy_p, gy_s, gzh_p, gzh_s, ptr(glq),
+                             _poff(glogits, i_off), W_in, B, K, tau, dt, st)
+                        k += 2
+                    else:
+                        call('vae_bernoulli_bwd', _poff(logits, i_off), rs, y_p, y_s, gy_p, gy_s, gzh_p, gzh_s,
+                             _poff(glogits, i_off), W_in, B, K, tau, dt, st)
+                        k += 1
+                    i_off, o_off = i_off + K, o_off + K
+        return glogits, None, None, None, None, None
+
+
+def concat_leaves(logits, specs, training, noises, seeds, row0=0):
+    """Run kernel-backed Concat children over one [B, sum(in)] logits buffer.  Returns the flat tuple
+    (zcat, then per child: gauss -> logvar, kl, means[2]; gumbel -> other, log_q_z; bern -> other), where
+    `other` is z_hard in training (y went into zcat) and y in eval (z_hard went into zcat)."""
+    logits = _rows(logits)
+    B = logits.shape[0]
+    fixed = []
+    for spec, n in zip(specs, noises):
+        if n is not None:
+            n = n.reshape(B, spec[1]).to(logits.dtype).contiguous()
+        fixed.append(n)
+    return _ConcatLeaves.apply(logits, tuple(specs), bool(training), tuple(fixed), tuple(seeds), int(row0))

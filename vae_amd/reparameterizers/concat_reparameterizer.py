@@ -5,6 +5,14 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import functional as F_
+from .. import rng
+from .bernoulli import Bernoulli
+from .gumbel import GumbelSoftmax
+from .isotropic_gaussian import EPS_TOL, IsotropicGaussian
+
+_FUSABLE = (IsotropicGaussian, GumbelSoftmax, Bernoulli)
+
 
 class ConcatReparameterizer(nn.Module):
     def __init__(self, reparam_strs, config):
@@ -39,14 +47,63 @@ class ConcatReparameterizer(nn.Module):
             kl = reparam.kl(param, prior) if kl is None else kl + reparam.kl(param, prior)
         return kl
 
+    def _forward_fused(self, logits, force, noise):
+        """All children are kernel-backed leaves on 2-D logits: one autograd node; every child reads its
+        strided slice of `logits`, writes its sample into the concatenated output and (backward) its gradient
+        into one shared d(logits) buffer.  Same returns as the generic path below."""
+        training = bool(self.training or force)
+        specs, seeds = [], []
+        for child, n in zip(self.reparameterizers, noise):
+            if isinstance(child, IsotropicGaussian):
+                specs.append(('gauss', child.output_size, EPS_TOL, child.mean_scale))
+            else:
+                child.anneal()   # host-side tau schedule, before the draw (gumbel.py:326, bernoulli.py:198)
+                specs.append(('gumbel' if isinstance(child, GumbelSoftmax) else 'bern', child.output_size,
+                              float(child.tau)))
+            seeds.append((0, 0) if (n is not None or (specs[-1][0] == 'gauss' and not training)) else rng.next_call())
+        row0 = self.reparameterizers[0].row_offset
+        outs = F_.concat_leaves(logits, specs, training, noise, seeds, row0=row0)
+        zcat, k = outs[0], 1
+        params_list, i_off, o_off = [], 0, 0
+        for child, spec in zip(self.reparameterizers, specs):
+            kind, n_out = spec[0], spec[1]
+            z_i = zcat[:, o_off:o_off + n_out]
+            if kind == 'gauss':
+                logits_i = logits[:, i_off:i_off + 2 * n_out]
+                mu = logits_i[:, :n_out]
+                logvar, kl, means = outs[k], outs[k + 1], outs[k + 2].to(logits.dtype)
+                logvar._vae_amd_kl = (kl, mu)
+                g = {'z': z_i, 'mu': mu, 'logvar': logvar, 'mu_mean': means[0], 'logvar_mean': means[1]}
+                params = {'z': z_i, 'logits': logits_i, 'gaussian': g}
+                k, i_off = k + 3, i_off + 2 * n_out
+            else:
+                logits_i = logits[:, i_off:i_off + n_out]
+                other = outs[k]
+                y, z_hard = (z_i, other) if training else (other, z_i)
+                d = {'z_hard': z_hard, 'logits': logits_i, 'tau_scalar': child.tau}
+                if kind == 'gumbel':
+                    d = {'z_hard': z_hard, 'logits': logits_i, 'log_q_z': outs[k + 1], 'tau_scalar': child.tau}
+                    params = {'z': y, 'discrete': d}
+                    k += 2
+                else:
+                    params = {'z': y, 'logits': logits_i, 'discrete': d}
+                    k += 1
+                child.iteration += 1
+                i_off += n_out
+            params_list.append({**params, 'logits': logits_i})
+            o_off += n_out
+        return zcat, {'logits': logits, 'concat': params_list}
+
     def forward(self, logits, force=False, noise=None):
         """`noise`: optional list with one injected noise tensor (or None) per child."""
+        noise = [None] * len(self.reparameterizers) if noise is None else noise
+        if logits.dim() == 2 and all(isinstance(r, _FUSABLE) for r in self.reparameterizers):
+            return self._forward_fused(logits, force, noise)
         params_list = []
         reparameterized = []
         dim_map = {2: -1, 3: -1, 4: 1}
         assert logits.dim() in dim_map, "unknown number of dims for concat reparam"
         dim2slice = dim_map[logits.dim()]
-        noise = [None] * len(self.reparameterizers) if noise is None else noise
         for i, (begin, end) in enumerate(zip(self._input_sizing, self._input_sizing[1:])):
             begin, end = int(begin), int(end)
             logits_i = torch.narrow(logits, dim2slice, begin, end - begin)

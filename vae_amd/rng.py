@@ -20,3 +20,11 @@ def next_call():
         _state['offset'] = 0
     _state['offset'] += 1
     return seed, _state['offset']
+
+
+def manual_seed(seed):
+    """torch.manual_seed + restart of the call counter (re-seeding torch with the SAME value cannot be
+    observed from here, so a script that replays a run inside one process calls this instead)."""
+    torch.manual_seed(seed)
+    _state['seed'] = torch.initial_seed()
+    _state['offset'] = 0
