@@ -109,6 +109,29 @@ def concat(B, L, K):
     timeit('concat fwd (gauss+gumbel)', 'B=%d L=%d K=%d f32, strided views of one logits buffer' % (B, L, K), fn, B * (16 * L + 4 + 20 * K))
 
 
+def concat_module(B, L, K):
+    """Whole ConcatReparameterizer step through the drop-in module (forward, kl, backward of z.w + kl):
+    the one-node strided path against the per-child path (narrow views, torch.cat, narrow-backward adds)."""
+    from vae_amd.reparameterizers import ConcatReparameterizer, concat_reparameterizer as C
+    W = 2 * L + K
+    logits = T(B, W).requires_grad_(True)
+    noise, w = [T(B, L), T(B, K, kind='rand')], T(B, L + K)
+    cfgd = {'continuous_size': 2 * L, 'discrete_size': K, 'cuda': True, 'half': False}
+    # fwd: logits, noise, zcat, logvar, z_hard, log_q_z, kl   bwd: gauss logits, eps, gz, y, log_q_z, d(logits)
+    nbytes = B * 4 * ((W + L + K + L + K + L + 2 * K + 1) + (2 * L + L + L + K + 2 * K + W))
+    fusable = C._FUSABLE
+    for label, fus in (('concat step (one node)', fusable), ('concat step (per child)', ())):
+        C._FUSABLE = fus
+        m = ConcatReparameterizer(['isotropic_gaussian', 'discrete'], dict(cfgd)).train()
+
+        def fn():
+            z, params = m(logits, noise=noise)
+            ((z * w).sum() + m.kl(params).sum()).backward()
+            logits.grad = None
+        timeit(label, 'B=%d L=%d K=%d f32 module fwd+kl+bwd (+ torch z*w sum)' % (B, L, K), fn, nbytes)
+    C._FUSABLE = fusable
+
+
 def bernoulli(B, K):
     logits, U, gy = T(B, K), T(B, K, kind='rand'), T(B, K)
     y, zh, gl, kl, gkl = T(B, K, kind='e'), T(B, K, kind='e'), T(B, K, kind='e'), T(B, kind='e'), T(B)
@@ -168,6 +191,7 @@ if __name__ == '__main__':
         gumbel(65536, K)
     gumbel(65536, 256, philox=True)
     concat(65536, 128, 256)
+    concat_module(65536, 128, 256)
     print('== C4: Gaussian->Flow, 3x64x64 discretized logistic')
     nll(8192, 12288, 2, 'disc_logistic')
     nll(8192, 12288, 1, 'gaussian')

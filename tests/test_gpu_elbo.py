@@ -86,6 +86,11 @@ def test_nll_elbo_vs_oracle(nll_type, shape):
     close(E.nll(x.to(DEV), rd, nll_type), n0, rtol=1e-5, atol=1e-6 * D)
     if nll_type == 'disc_logistic':
         close_cond(g1r, g0r, g64r)
+    elif nll_type == 'gaussian':
+        # d/dv = (1/s - d^2/s) sigmoid(v) cancels where |x - m| ~ s: accuracy judged against fp64 like the
+        # oracle's own (close_cond), plus a loose elementwise bound
+        close_cond(g1r, g0r, g64r)
+        close(g1r, g0r, rtol=1e-4, atol=1e-5)
     else:
         close(g1r, g0r, rtol=1e-5, atol=2e-6)
     close(g1k, g0k, rtol=1e-5, atol=1e-6)

@@ -109,7 +109,10 @@ __global__ __launch_bounds__(kBlock) void bernoulli_bwd_kernel(
   }
 }
 
-template <typename T, int V, int U, bool BWD>
+// q via t = exp(-|l|), r = 1/(1+t): the larger of (q1, q0) is r, the smaller t*r (no 1-q cancellation, one
+// exp + one rcp for both); with no prior the summand is symmetric in the sign of l, so no select is needed.
+// Two logs per element remain because of the +1e-6 inside them.  HASP = prior logits given.
+template <typename T, int V, int U, bool BWD, bool HASP>
 __global__ __launch_bounds__(kBlock) void bernoulli_kl_kernel(
     const T* __restrict__ lq, int64_t stride_q, const T* __restrict__ lp, int64_t stride_p,
     const T* __restrict__ gkl, T* __restrict__ kl, T* __restrict__ gq, T* __restrict__ gp, int64_t B, int K, int G,
@@ -118,16 +121,16 @@ __global__ __launch_bounds__(kBlock) void bernoulli_kl_kernel(
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = K / V;
+  const float lhalf = __logf(0.5f + kBernKlEps);  // both prior terms when no prior logits are given
   for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
     const int64_t row = t * rpb + rloc;
     float acc = 0.f;
     if (row < B) {
       const float gk = BWD ? to_f32(gkl[row]) : 0.f;
-      const float lhalf = __logf(0.5f + kBernKlEps);  // both prior terms when no prior logits are given
       for (int j0 = sub; j0 < nvec; j0 += G * U) {
         float a[U][V], b[U][V];
         load_chunk<T, V, U>(lq + row * stride_q, j0, G, nvec, a);
-        if (lp) load_chunk<T, V, U>(lp + row * stride_p, j0, G, nvec, b);
+        if constexpr (HASP) load_chunk<T, V, U>(lp + row * stride_p, j0, G, nvec, b);
 #pragma unroll
         for (int k = 0; k < U; ++k) {
           const int j = j0 + k * G;
@@ -135,21 +138,39 @@ __global__ __launch_bounds__(kBlock) void bernoulli_kl_kernel(
             float oq[V], op[V];
 #pragma unroll
             for (int i = 0; i < V; ++i) {
-              const float q1 = sigmoid_div(a[k][i]), q0 = 1.0f - q1;
-              const float p1 = lp ? sigmoid_div(b[k][i]) : 0.5f, p0 = 1.0f - p1;
-              const float d1 = __logf(q1 + kBernKlEps) - (lp ? __logf(p1 + kBernKlEps) : lhalf);
-              const float d0 = __logf(q0 + kBernKlEps) - (lp ? __logf(p0 + kBernKlEps) : lhalf);
-              if constexpr (!BWD) {
-                acc += q1 * d1 + q0 * d0;
+              const float tq = __expf(-fabsf(a[k][i])), rq = fast_rcp(1.0f + tq);
+              const float qb = rq, qs = tq * rq;  // larger / smaller of (q1, q0)
+              const float lb = fast_log(qb + kBernKlEps), ls = fast_log(qs + kBernKlEps);
+              if constexpr (!HASP) {
+                if constexpr (!BWD) {
+                  acc += qb * (lb - lhalf) + qs * (ls - lhalf);
+                } else {
+                  // d/dl of the summand, written for l >= 0 (q1 = qb) and mirrored for l < 0
+                  const float d = (lb + qb * fast_rcp(qb + kBernKlEps)) - (ls + qs * fast_rcp(qs + kBernKlEps));
+                  oq[i] = gk * copysignf(d * qb * qs, a[k][i]);
+                }
               } else {
-                const float dq1 = d1 + q1 * fast_rcp(q1 + kBernKlEps) - d0 - q0 * fast_rcp(q0 + kBernKlEps);
-                oq[i] = gk * dq1 * q1 * q0;
-                op[i] = gk * (q0 * fast_rcp(p0 + kBernKlEps) - q1 * fast_rcp(p1 + kBernKlEps)) * p1 * p0;
+                const bool posq = a[k][i] >= 0.f;
+                const float q1 = posq ? qb : qs, q0 = posq ? qs : qb;
+                const float lq1 = posq ? lb : ls, lq0 = posq ? ls : lb;
+                const float tp = __expf(-fabsf(b[k][i])), rp = fast_rcp(1.0f + tp);
+                const bool posp = b[k][i] >= 0.f;
+                const float p1 = posp ? rp : tp * rp, p0 = posp ? tp * rp : rp;
+                const float d1 = lq1 - fast_log(p1 + kBernKlEps), d0 = lq0 - fast_log(p0 + kBernKlEps);
+                if constexpr (!BWD) {
+                  acc += q1 * d1 + q0 * d0;
+                } else {
+                  const float dq1 = d1 + q1 * fast_rcp(q1 + kBernKlEps) - d0 - q0 * fast_rcp(q0 + kBernKlEps);
+                  oq[i] = gk * dq1 * q1 * q0;
+                  op[i] = gk * (q0 * fast_rcp(p0 + kBernKlEps) - q1 * fast_rcp(p1 + kBernKlEps)) * p1 * p0;
+                }
               }
             }
             if constexpr (BWD) {
               store_vec<T, V>(gq + row * K + (int64_t)j * V, oq);
-              if (gp && lp) store_vec<T, V>(gp + row * K + (int64_t)j * V, op);
+              if constexpr (HASP) {
+                if (gp) store_vec<T, V>(gp + row * K + (int64_t)j * V, op);
+              }
             }
           }
         }
@@ -202,15 +223,16 @@ static int bern_kl_dispatch(const void* lq, int64_t sq, const void* lp, int64_t 
   bool vec = (K % VN == 0) && (sq % VN == 0) && aligned16(lq) && (!lp || ((sp % VN == 0) && aligned16(lp)));
   if (BWD) vec = vec && aligned16(gq) && (!gp || aligned16(gp));
   const RowGeom g = row_geom(B, vec ? K / VN : K, kGridStream);
+#define BERN_KL_GO(VV, HP)                                                                                          \
+  VAE_SWITCH_U(g.U, hipLaunchKernelGGL((bernoulli_kl_kernel<T, VV, U, BWD, HP>), dim3(g.grid), dim3(kBlock), 0, stream, \
+                                       (const T*)lq, sq, (const T*)lp, sp, (const T*)gkl, (T*)kl, (T*)gq, (T*)gp, B,    \
+                                       (int)K, g.G, g.tiles))
   if (vec) {
-    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((bernoulli_kl_kernel<T, VN, U, BWD>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                         (const T*)lq, sq, (const T*)lp, sp, (const T*)gkl, (T*)kl, (T*)gq, (T*)gp, B,
-                                         (int)K, g.G, g.tiles));
+    if (lp) { BERN_KL_GO(VN, true); } else { BERN_KL_GO(VN, false); }
   } else {
-    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((bernoulli_kl_kernel<T, 1, U, BWD>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                         (const T*)lq, sq, (const T*)lp, sp, (const T*)gkl, (T*)kl, (T*)gq, (T*)gp, B,
-                                         (int)K, g.G, g.tiles));
+    if (lp) { BERN_KL_GO(1, true); } else { BERN_KL_GO(1, false); }
   }
+#undef BERN_KL_GO
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 

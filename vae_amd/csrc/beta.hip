@@ -35,10 +35,10 @@ __device__ __forceinline__ void gamma_fns(float x, float& lg, float& psi, float&
     }
   }
   const float i = fast_rcp(x), i2 = i * i;
-  const float lx = __logf(x);
+  const float lx = fast_log(x);
   if (LG)
     lg = (x - 0.5f) * lx - x + 0.91893853320467274178f + i * (1.0f / 12.0f - i2 * (1.0f / 360.0f - i2 * (1.0f / 1260.0f))) -
-         __logf(prod);
+         fast_log(prod);
   if (PSI) psi = lx - 0.5f * i - i2 * (1.0f / 12.0f - i2 * (1.0f / 120.0f - i2 * (1.0f / 252.0f))) - r1;
   if (TRI) tri = i + 0.5f * i2 + i * i2 * (1.0f / 6.0f - i2 * (1.0f / 30.0f - i2 * (1.0f / 42.0f))) + r2;
 }

@@ -161,9 +161,18 @@ __device__ __forceinline__ float rcp_nr(float d) {
   const float r = __builtin_amdgcn_rcpf(d);
   return r * (2.0f - d * r);
 }
+// ln(x) for x in the NORMAL float range: bare v_log_f32 (log2, 1 ulp) times ln 2.  hipcc's __logf wraps the
+// same instruction in denormal scaling and a compensated multiply (~12 VALU ops instead of 2), which made the
+// Bernoulli NLL forward issue-bound (672 G elements/s).  Callers guarantee x >= ~1e-30 or accept -inf at 0.
+constexpr float kLn2 = 0.693147180559945309f;
+constexpr float kLog2e = 1.44269504088896341f;
+__device__ __forceinline__ float log2_raw(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fast_log(float x) { return kLn2 * __builtin_amdgcn_logf(x); }
+// e^x for x <= ~80 with a result in the normal range or flushing to 0 (bare v_exp_f32)
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
 // log(1 + e) for e in [0, 1]
 __device__ __forceinline__ float log1p_unit(float e) {
-  return e < 1e-3f ? e * (1.0f - e * (0.5f - e * (1.0f / 3.0f))) : __logf(1.0f + e);
+  return e < 1e-3f ? e * (1.0f - e * (0.5f - e * (1.0f / 3.0f))) : fast_log(1.0f + e);
 }
 
 // log(1 + e) for any e >= 0 with full RELATIVE precision (Kahan: log(u) * e / (u - 1), u = fl(1 + e));
@@ -171,7 +180,7 @@ __device__ __forceinline__ float log1p_unit(float e) {
 __device__ __forceinline__ float log1p_unit_any(float e) {
   const float u = 1.0f + e;
   const float d = u - 1.0f;
-  return d == 0.0f ? e : __logf(u) * (e * fast_rcp(d));
+  return d == 0.0f ? e : fast_log(u) * (e * fast_rcp(d));
 }
 
 // Sum / max over the G lanes that share a row (G power of two, <= 64).  After the
@@ -353,7 +362,7 @@ __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5
 __device__ __forceinline__ void normal4(const uint32_t (&w)[4], float (&n)[4]) {
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    float r = sqrtf(-2.0f * __logf(u01(w[2 * p])));
+    float r = sqrtf(-2.0f * fast_log(u01(w[2 * p])));
     float s, c;
     __sincosf(6.283185307179586f * u01(w[2 * p + 1]), &s, &c);
     n[2 * p] = r * c;

@@ -49,7 +49,7 @@ __device__ __forceinline__ float softplusf_(float v) {
 // is below the rounding of max(l,0) - l*x itself, and the exact ocml forms cost 15 % of this
 // kernel's time (measured: 4.5 -> 5.1 TB/s).
 __device__ __forceinline__ float nll_bern(float x, float l) {
-  return fmaxf(l, 0.0f) - l * x + __logf(1.0f + __expf(-fabsf(l)));
+  return fmaxf(l, 0.0f) - l * x + fast_log(1.0f + fast_exp(-fabsf(l)));
 }
 __device__ __forceinline__ float nll_bern_grad(float x, float l) { return fast_rcp(1.0f + __expf(-l)) - x; }
 
@@ -57,7 +57,7 @@ __device__ __forceinline__ float nll_bern_grad(float x, float l) { return fast_r
 __device__ __forceinline__ float nll_gauss(float x, float m, float v) {
   const float s = softplusf_(v) + 1e-6f;
   const float d = (x - m) * rcp_nr(s);
-  return 0.5f * d * d + __logf(s) + kHalfLog2Pi;
+  return 0.5f * d * d + fast_log(s) + kHalfLog2Pi;
 }
 __device__ __forceinline__ void nll_gauss_grad(float x, float m, float v, float& gm, float& gv) {
   const float s = softplusf_(v) + 1e-6f;
@@ -77,7 +77,7 @@ __device__ __forceinline__ float nll_dlog(float x, float a, float v) {
   const float t = (xq - m) * isc;
   const float cp = sigmoid_acc(t + kBin * isc);
   const float cm = sigmoid_acc(t);
-  return -__logf(cp - cm + 1e-7f);
+  return -fast_log(cp - cm + 1e-7f);
 }
 __device__ __forceinline__ void nll_dlog_grad(float x, float a, float v, float& ga, float& gv) {
   const float xq = floorf(x * 256.0f) * kBin;

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(kBlock) void gauss_fwd_kernel(
                           ? add_rn(to_f32(from_f32<T>(mul_rn(e[u][i], to_f32(from_f32<T>(mul_rn(0.5f, si)))))), m)
                           : m;
               const float s2 = si * si;
-              klr += 0.5f * (s2 + m * m - 1.0f - __logf(s2));
+              // log(s^2) = 2 ln2 log2|s|: |s| = |raw + eps_tol| is 0 or >= 1e-13, so bare v_log_f32 is safe
+              klr += 0.5f * (s2 + m * m - 1.0f) - kLn2 * log2_raw(fabsf(si));
               acc[0] += m;
               acc[1] += si;
             }
@@ -165,13 +166,14 @@ __global__ __launch_bounds__(kBlock) void gauss_kl_fwd_kernel(
         for (int i = 0; i < V; ++i) {
           if (mu_p) {
             // torch kl_normal_normal: var_ratio = (sq/sp)^2; t1 = ((mq-mp)/sp)^2
-            float r = sq[i] / sp[i];
+            const float isp = rcp_nr(sp[i]);
+            float r = sq[i] * isp;
             float vr = r * r;
-            float d = (mq[i] - mp[i]) / sp[i];
-            klr += 0.5f * (vr + d * d - 1.0f - logf(vr));
+            float d = (mq[i] - mp[i]) * isp;
+            klr += 0.5f * (vr + d * d - 1.0f - fast_log(vr));
           } else {
             float s2 = sq[i] * sq[i];
-            klr += 0.5f * (s2 + mq[i] * mq[i] - 1.0f - logf(s2));
+            klr += 0.5f * (s2 + mq[i] * mq[i] - 1.0f - fast_log(s2));
           }
         }
       }

@@ -70,9 +70,9 @@ __global__ __launch_bounds__(kBlock) void gauss_pair_fwd_kernel(
               const float r = lq * ip;
               const float vr = r * r;
               const float d = (a - b) * ip;
-              kp += 0.5f * (vr + d * d - 1.0f - __logf(vr));
+              kp += 0.5f * (vr + d * d - 1.0f - fast_log(vr));
               const float lp2 = lp * lp;
-              k0 += 0.5f * (lp2 + b * b - 1.0f - __logf(lp2));
+              k0 += 0.5f * (lp2 + b * b - 1.0f - fast_log(lp2));
               acc[0] += a; acc[1] += lq; acc[2] += b; acc[3] += lp;
               eq[u][i] = lp;  // reuse as the logvar_prior store buffer
             }
