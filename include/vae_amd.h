@@ -45,6 +45,7 @@ enum { VAE_NLL_BERNOULLI = 0, VAE_NLL_GAUSSIAN = 1, VAE_NLL_DISC_LOGISTIC = 2 };
 /* softmax-class kernels keep the row in registers: 4 x 256 16-byte vectors (fp32; bf16 rows
  * may be twice as long when K % 8 == 0); unaligned rows (K % 4 != 0) are limited to 1024.   */
 #define VAE_MAX_SOFTMAX_ROW 4096
+#define VAE_MAX_SAMPLES 8   /* decoder outputs one vae_nll_multi_elbo_* call combines */
 
 /* ABI version of this header; bumped on any signature change. */
 int vae_abi_version(void);
@@ -212,6 +213,38 @@ int vae_elbo_combine_fwd(const void* nll, const void* kld, const void* add, cons
                          int dtype, vae_stream_t stream);
 int vae_elbo_combine_bwd(const void* gloss, const void* gelbo, const float* gmeans, float kl_beta, float inv_count,
                          void* gnll, void* gkld, void* gadd, void* gmi, int64_t B, int dtype, vae_stream_t stream);
+
+/* ---- multi-sample forms ("same logits, many noises") --------------------------
+ * Replace the draw loops of abstract_vae.py:347-354 (loss_function K > 1),
+ * msg.py:55-69 (MSGVAE.reparameterize, max_time_steps draws) and
+ * abstract_vae.py:301-311 (likelihood): S training-mode draws
+ *   z[s] = noise[s] * (0.5*s) + mu,  s = 0..S-1
+ * from ONE read of logits; logvar, kl and the two means as in
+ * vae_gauss_reparam_kl_fwd (they do not depend on the draw).
+ *   noise [S, B, L] or NULL (in-kernel Philox; draw s uses call offset `offset + s`,
+ *   i.e. the streams S consecutive single calls would use); z [S, B, L] contiguous. */
+int vae_gauss_reparam_multi_fwd(const void* logits, int64_t row_stride, const void* noise, void* z, void* s_out,
+                                void* kl, float* means, float* workspace, int64_t B, int64_t L, int64_t S,
+                                float eps_tol, float mean_scale, uint64_t seed, uint64_t offset, int64_t row0,
+                                int dtype, vae_stream_t stream);
+/* gz [S, B, L] or NULL; glogits [B, 2L] contiguous: d mu = sum_s gz[s] + ..., d s = 0.5 sum_s noise[s] gz[s] + ... */
+int vae_gauss_reparam_multi_bwd(const void* logits, int64_t row_stride, const void* noise, const void* gz,
+                                const void* gs, const void* gkl, const float* gmeans, void* glogits, int64_t B,
+                                int64_t L, int64_t S, float eps_tol, float mean_scale, uint64_t seed, uint64_t offset,
+                                int64_t row0, int dtype, vae_stream_t stream);
+/* S-sample NLL + ELBO (abstract_vae.py:344-354 then :356-388):
+ *   nll[b] = (1/S) sum_s nll(x[b], recons[s][b]);  x is read once.
+ * recons: HOST array of S device pointers (1 <= S <= VAE_MAX_SAMPLES), each a contiguous
+ * [B, D] / [B, 2D] decoder output; everything else as vae_nll_elbo_fwd.            */
+int vae_nll_multi_elbo_fwd(const void* x, const void* const* recons, int64_t S, int nll_type, const void* kld,
+                           const void* add, const void* mi, float kl_beta, float inv_count, void* nll, void* loss,
+                           void* elbo, float* means, float* workspace, int64_t B, int64_t D, int dtype,
+                           vae_stream_t stream);
+/* grecons: HOST array of S device pointers, each written with d/d recons[s].       */
+int vae_nll_multi_elbo_bwd(const void* x, const void* const* recons, void* const* grecons, int64_t S, int nll_type,
+                           const void* gnll, const void* gloss, const void* gelbo, const float* gmeans, float kl_beta,
+                           float inv_count, void* gkld, void* gadd, void* gmi, int64_t B, int64_t D, int dtype,
+                           vae_stream_t stream);
 
 #ifdef __cplusplus
 }

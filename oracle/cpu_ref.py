@@ -259,6 +259,27 @@ def loss_function(nll_, kld, kl_beta=1.0, mut_info=None, extra=None):
 
 
 # --------------------------------------------------------------------------------- vrnn
+def nll_multi(x, recon_list, nll_type):
+    """abstract_vae.py:344-354: nll of the first decode, += nll of each further draw's decode, / K."""
+    out = nll(x, recon_list[0], nll_type)
+    for r in recon_list[1:]:
+        out = out + nll(x, r, nll_type)
+    return out / len(recon_list)
+
+
+def gauss_forward_multi(logits, noises, eps_tol=EPS_TOL):
+    """msg.py:63-69 / abstract_vae.py:348-350: the reparameterizer called once per draw on the same logits."""
+    pairs = [gauss_forward(logits, n, training=True, eps_tol=eps_tol) for n in noises]
+    return [p[0] for p in pairs], [p[1] for p in pairs]
+
+
+def iwae_estimate(elbos, count):
+    """abstract_vae.py:313-315: logsumexp of the stacked elbo values minus log(count + 1), where `count` is
+    the last index of the draw loop (NOT the number of values: each of the K // B passes contributes B)."""
+    flat = torch.cat([e.unsqueeze(0) for e in elbos], 0).view([-1])
+    return torch.logsumexp(flat, dim=0) - math.log(count + 1)
+
+
 def clamp_variance(logits):
     """vrnn.py:395-408 (isotropic_gaussian branch)."""
     feat = logits.size(-1)

@@ -132,6 +132,29 @@ def concat_module(B, L, K):
     C._FUSABLE = fusable
 
 
+def multi(B, L, D, S):
+    """(f)2 multi-sample forms: S draws from one logits read; S decoder outputs against one read of x."""
+    logits, noise, gz = T(B, 2 * L), T(S, B, L), T(S, B, L)
+    z, lv, kl, gkl, gl = T(S, B, L, kind='e'), T(B, L, kind='e'), T(B, kind='e'), T(B), T(B, 2 * L, kind='e')
+    means = torch.zeros(2, device=dev)
+    cfg = 'B=%d L=%d S=%d f32' % (B, L, S)
+    timeit('gauss_multi_fwd', cfg, lambda: call('vae_gauss_reparam_multi_fwd', ptr(logits), 2 * L, ptr(noise), ptr(z), ptr(lv), ptr(kl), ptr(means), ptr(ws), B, L, S, 1e-6, 1.0 / (B * L), 0, 0, 0, 0, st),
+           B * (8 * L + 4 * L + S * 8 * L + 4))       # logits + logvar + S (noise + z) + kl
+    timeit('gauss_multi_bwd', cfg, lambda: call('vae_gauss_reparam_multi_bwd', ptr(logits), 2 * L, ptr(noise), ptr(gz), None, ptr(gkl), None, ptr(gl), B, L, S, 1e-6, 1.0 / (B * L), 0, 0, 0, 0, st),
+           B * (8 * L + S * 8 * L + 8 * L + 4))       # logits + S (noise + gz) + glogits
+    x = (T(B, D, kind='rand') < 0.13).float()
+    recons, grecons = [T(B, D) for _ in range(S)], [T(B, D, kind='e') for _ in range(S)]
+    kld, n, lo, el = T(B, kind='rand'), T(B, kind='e'), T(B, kind='e'), T(B, kind='e')
+    m6, gm = torch.zeros(6, device=dev), torch.zeros(6, device=dev)
+    gm[0] = 1
+    rp, gp = _lib.ptr_array(recons), _lib.ptr_array(grecons)
+    cfg = 'B=%d D=%d S=%d bernoulli f32' % (B, D, S)
+    timeit('nll_multi_elbo_fwd', cfg, lambda: call('vae_nll_multi_elbo_fwd', ptr(x), rp, S, 0, ptr(kld), None, None, 1.0, 1.0 / B, ptr(n), ptr(lo), ptr(el), ptr(m6), ptr(ws), B, D, 0, st),
+           B * (4 * D + S * 4 * D + 12))
+    timeit('nll_multi_elbo_bwd', cfg, lambda: call('vae_nll_multi_elbo_bwd', ptr(x), rp, gp, S, 0, None, None, None, ptr(gm), 1.0, 1.0 / B, None, None, None, B, D, 0, st),
+           B * (4 * D + S * 8 * D))
+
+
 def bernoulli(B, K):
     logits, U, gy = T(B, K), T(B, K, kind='rand'), T(B, K)
     y, zh, gl, kl, gkl = T(B, K, kind='e'), T(B, K, kind='e'), T(B, K, kind='e'), T(B, kind='e'), T(B)
@@ -202,6 +225,9 @@ if __name__ == '__main__':
     pair_fused(16384, 128)
     pair_fused(4096, 32)
     nll(64 * 1024, 784, 0, 'bernoulli T=64 x B=1024')
+    print('== multi-sample forms (loss_function K > 1, MSGVAE, likelihood)')
+    multi(65536, 512, 784, 4)
+    multi(16384, 128, 784, 8)
     print('== Bernoulli / Beta reparameterizers')
     bernoulli(65536, 1024)
     beta(65536, 512)

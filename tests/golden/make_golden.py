@@ -411,6 +411,88 @@ def make_vrnn(vae, out):
     out['vrnn'] = {'steps': steps, 'losses': detach_tree(losses), 'mean_map': detach_tree(agg)}
 
 
+def make_multi(vae, out):
+    """The draw loops: loss_function(K=3) in training (abstract_vae.py:347-354), MSGVAE.reparameterize
+    (msg.py:55-69) and likelihood (abstract_vae.py:281-317), each called unbound on a stub.  The NLL is the
+    stub's own (Bernoulli via torch.distributions; helpers is absent): these fixtures pin the draw order, the
+    K-average and the log-sum-exp normalisation, not an NLL definition."""
+    AV = sys.modules['models.vae.abstract_vae'].AbstractVAE
+    MSG = sys.modules['models.vae.msg'].MSGVAE
+    R = vae.reparameterizers
+    B, L, Dx = 8, 4, 12
+    cfg = base_config(continuous_size=2 * L, nll_type='bernoulli', max_time_steps=3)
+    torch.manual_seed(1100)
+    dec = nn.Linear(L, Dx)
+    enc = nn.Linear(Dx, 2 * L)
+
+    class Stub(object):
+        training = True
+        config = cfg
+        kl_annealer = None
+        reparameterizer = R.IsotropicGaussian(cfg)
+        compute_kl_beta = AV.compute_kl_beta
+        loss_function = AV.loss_function
+
+        def reparameterize(self, logits, labels=None, force=False):
+            return self.reparameterizer(logits, force=force)
+
+        def decode(self, z):
+            return dec(z)
+
+        def encode(self, x):
+            return enc(x)
+
+        def nll(self, x, recon_x, nll_type):
+            return -torch.sum(D.Bernoulli(logits=recon_x).log_prob(x), -1)
+
+        def kld(self, p):
+            return self.reparameterizer.kl(p)
+
+        def mut_info(self, p, b):
+            return torch.zeros(b)
+
+    st = Stub()
+    st.reparameterizer.train(True)
+    x = (torch.rand(B, Dx) < 0.3).float()
+    logits = torch.randn(B, 2 * L, requires_grad=True)
+    K = 3
+    torch.manual_seed(21)
+    noises = [torch.zeros(B, L).normal_() for _ in range(K)]
+    torch.manual_seed(21)
+    z0, params = st.reparameterize(logits)
+    res = AV.loss_function(st, st.decode(z0), x, params, K=K)
+    g_logits, g_w, g_b = torch.autograd.grad(res['loss_mean'], [logits, dec.weight, dec.bias])
+    out['multi_lossK3'] = detach_tree({
+        'x': x, 'logits': logits, 'noises': noises, 'K': K, 'dec_weight': dec.weight, 'dec_bias': dec.bias,
+        'result': res, 'grad_logits': g_logits, 'grad_dec_weight': g_w, 'grad_dec_bias': g_b})
+
+    # MSGVAE.reparameterize + kld (last parameter set)
+    torch.manual_seed(22)
+    noises = [torch.zeros(B, L).normal_() for _ in range(3)]
+    torch.manual_seed(22)
+    z_list, p_list = MSG.reparameterize(st, logits)
+    kl = MSG.kld(st, p_list)
+    w = torch.randn(3, B, L)
+    (g,) = torch.autograd.grad(sum((z * wi).sum() for z, wi in zip(z_list, w)) + kl.sum(), logits)
+    out['multi_msg'] = detach_tree({'logits': logits, 'noises': noises, 'z_list': z_list, 'params_last': p_list[-1],
+                                    'kl': kl, 'w': w, 'grad_logits': g})
+
+    # likelihood: model in eval (loss_function takes no extra draws), reparameterizer left in TRAIN mode in one
+    # case so the draws are stochastic, and in eval in the other (z = mu: every value identical)
+    Bl, Kl = 4, 8
+    xb = (torch.rand(Bl, Dx) < 0.3).float()
+    for mode in (True, False):
+        st.training = False
+        st.reparameterizer.train(mode)
+        torch.manual_seed(23)
+        noises = [torch.zeros(Bl, L).normal_() for _ in range(Bl * (Kl // Bl))]
+        torch.manual_seed(23)
+        val = AV.likelihood(st, [(xb, torch.zeros(Bl).long())], K=Kl)
+        out['multi_likelihood_%s' % ('draws' if mode else 'mean')] = detach_tree({
+            'x': xb, 'K': Kl, 'noises': noises if mode else None, 'enc_weight': enc.weight, 'enc_bias': enc.bias,
+            'dec_weight': dec.weight, 'dec_bias': dec.bias, 'value': val, 'reparam_training': mode})
+
+
 def main():
     vae = install_reference()
     out = {}
@@ -423,6 +505,7 @@ def main():
     make_sequential(vae, out)
     make_elbo(vae, out)
     make_vrnn(vae, out)
+    make_multi(vae, out)
     groups = {}
     for k, v in out.items():
         groups.setdefault(k.split('_')[0], {})[k] = v

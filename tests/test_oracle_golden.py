@@ -194,3 +194,54 @@ def test_vrnn(golden):
             close(agg[k], v, rtol=1e-6, atol=0)
         else:
             assert agg[k] == pytest.approx(v)
+
+
+def test_multi_loss_k3(golden):
+    """abstract_vae.py:347-354 through the reference (stub model): draw order, K-average, combine."""
+    g = golden('multi')['multi_lossK3']
+    logits = g['logits'].clone().requires_grad_(True)
+    W, b = g['dec_weight'].clone().requires_grad_(True), g['dec_bias'].clone().requires_grad_(True)
+    z_list, p_list = O.gauss_forward_multi(logits, g['noises'])
+    recons = [torch.nn.functional.linear(z, W, b) for z in z_list]
+    nll = O.nll_multi(g['x'], recons, 'bernoulli')
+    res = O.loss_function(nll, O.gauss_kl(p_list[0]), 1.0)
+    for k, v in g['result'].items():
+        if torch.is_tensor(v):
+            close(res[k], v)
+        else:
+            assert res[k] == v
+    gl, gw, gb = torch.autograd.grad(res['loss_mean'], [logits, W, b])
+    close(gl, g['grad_logits'])
+    close(gw, g['grad_dec_weight'])
+    close(gb, g['grad_dec_bias'])
+
+
+def test_multi_msg(golden):
+    g = golden('multi')['multi_msg']
+    z_list, p_list = O.gauss_forward_multi(g['logits'], g['noises'])
+    for z, zr in zip(z_list, g['z_list']):
+        assert torch.equal(z, zr)
+    assert torch.equal(O.gauss_kl(p_list[-1]), g['kl'])
+    assert torch.equal(p_list[-1]['gaussian']['logvar'], g['params_last']['gaussian']['logvar'])
+
+
+@pytest.mark.parametrize('name', ['multi_likelihood_draws', 'multi_likelihood_mean'])
+def test_multi_likelihood(golden, name):
+    """abstract_vae.py:281-317: expand-one-sample batches, K // B passes, logsumexp - log(K // B)."""
+    g = golden('multi')[name]
+    x = g['x']
+    B = x.shape[0]
+    lin = torch.nn.functional.linear
+    z_logits = lin(x, g['enc_weight'], g['enc_bias'])
+    noises = iter(g['noises'] or [])
+    vals = []
+    for idx in range(B):
+        li = z_logits[idx].expand_as(z_logits).contiguous()
+        xi = x[idx].expand_as(x).contiguous()
+        elbos = []
+        for count in range(g['K'] // B):
+            z, p = O.gauss_forward(li, next(noises) if g['reparam_training'] else None, training=g['reparam_training'])
+            nll = O.nll(xi, lin(z, g['dec_weight'], g['dec_bias']), 'bernoulli')
+            elbos.append(O.loss_function(nll, O.gauss_kl(p), 1.0)['elbo'])
+        vals.append(O.iwae_estimate(elbos, count))
+    close(torch.mean(torch.stack(vals)), g['value'])

@@ -21,6 +21,7 @@ VAE_F32, VAE_BF16 = 0, 1
 NLL_TYPES = {'bernoulli': 0, 'gaussian': 1, 'disc_logistic': 2, 'log_logistic_256': 2}
 
 _p, _i64, _u64, _f, _i = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, ctypes.c_int
+_pp = ctypes.POINTER(ctypes.c_void_p)   # host array of device pointers
 
 # name -> argtypes; mirrors include/vae_amd.h one to one (tests/test_abi.py checks the symbols)
 SIGNATURES = {
@@ -54,6 +55,11 @@ SIGNATURES = {
     'vae_nll_elbo_bwd': [_p, _p, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i64, _i, _p],
     'vae_elbo_combine_fwd': [_p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i, _p],
     'vae_elbo_combine_bwd': [_p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i, _p],
+    'vae_gauss_reparam_multi_fwd': [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _f, _u64, _u64, _i64, _i, _p],
+    'vae_gauss_reparam_multi_bwd': [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _f, _u64, _u64, _i64, _i,
+                                    _p],
+    'vae_nll_multi_elbo_fwd': [_p, _pp, _i64, _i, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
+    'vae_nll_multi_elbo_bwd': [_p, _pp, _pp, _i64, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i64, _i64, _i, _p],
 }
 
 _lib = None
@@ -107,6 +113,11 @@ def check_device(*tensors):
 
 def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    """Host array of device pointers (the multi-sample NLL takes its S decoder outputs this way)."""
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
 def stream_ptr(device):

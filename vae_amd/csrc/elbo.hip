@@ -15,12 +15,11 @@
 // owned by G lanes (G <= 64: shuffles only) or by the whole block (G = 256: wave
 // shuffles, then LDS across the four waves) when rows are long and few.
 #include "common.hpp"
+#include "nll_math.hpp"
 #include "../../include/vae_amd.h"
 
 namespace vae {
 
-constexpr float kHalfLog2Pi = 0.91893853320467274178f;
-constexpr float kBin = 1.0f / 256.0f;
 // Load policy per kernel (tuning knobs).  Measured in the bench.py sequence (r01): temporal loads in any one of
 // the four hot kernels slow that kernel by 25-30 % and only shift ~10 % of time out of its successor; walking the
 // backward's rows in reverse (to hit what the forward left in the Infinity Cache) changed nothing -- nt loads do
@@ -32,68 +31,6 @@ constexpr float kBin = 1.0f / 256.0f;
 #define VAE_NT_NLL_BWD 1
 #endif
 constexpr bool kNtNllFwd = VAE_NT_NLL_FWD != 0, kNtNllBwd = VAE_NT_NLL_BWD != 0;
-
-__device__ __forceinline__ float sigmoidf_(float v) { return fast_rcp(1.0f + __expf(-v)); }
-// sigmoid for the discretized logistic, whose two CDF values are subtracted from each other (an
-// ulp there is amplified by 1/P): accurate exp, near-correctly-rounded reciprocal.
-__device__ __forceinline__ float sigmoid_acc(float v) { return rcp_nr(1.0f + expf(-v)); }
-// softplus(v) = log(1 + e^v): linear above 20 (torch.nn.functional.softplus), series for tiny e^v
-__device__ __forceinline__ float softplusf_(float v) {
-  const float e = __expf(fminf(v, 20.0f));
-  return v > 20.0f ? v : log1p_unit_any(e);
-}
-
-// ---- the three NLLs: value and d/d(recon) per element --------------------------
-// NLL == VAE_NLL_BERNOULLI: -Bernoulli(logits=l).log_prob(x) = max(l,0) - l*x + log1p(exp(-|l|))
-// The softplus term uses v_exp_f32 / v_log_f32 directly: its absolute error (<= ~1e-7 per element)
-// is below the rounding of max(l,0) - l*x itself, and the exact ocml forms cost 15 % of this
-// kernel's time (measured: 4.5 -> 5.1 TB/s).
-__device__ __forceinline__ float nll_bern(float x, float l) {
-  return fmaxf(l, 0.0f) - l * x + fast_log(1.0f + fast_exp(-fabsf(l)));
-}
-__device__ __forceinline__ float nll_bern_grad(float x, float l) { return fast_rcp(1.0f + __expf(-l)) - x; }
-
-// NLL == VAE_NLL_GAUSSIAN: -Normal(m, softplus(v) + 1e-6).log_prob(x)
-__device__ __forceinline__ float nll_gauss(float x, float m, float v) {
-  const float s = softplusf_(v) + 1e-6f;
-  const float d = (x - m) * rcp_nr(s);
-  return 0.5f * d * d + fast_log(s) + kHalfLog2Pi;
-}
-__device__ __forceinline__ void nll_gauss_grad(float x, float m, float v, float& gm, float& gv) {
-  const float s = softplusf_(v) + 1e-6f;
-  const float is = rcp_nr(s);
-  const float d = (x - m) * is;
-  gm = -d * is;
-  gv = (is - d * d * is) * sigmoidf_(v);
-}
-
-// NLL == VAE_NLL_DISC_LOGISTIC (256 bins): xq = floor(x*256)/256, m = sigmoid(a),
-// lv = clamp(v, -4.5, 0), 1/sc = exp(-lv), t = (xq - m)/sc,
-// -log(sigmoid(t + bin/sc) - sigmoid(t) + 1e-7)
-__device__ __forceinline__ float nll_dlog(float x, float a, float v) {
-  const float xq = floorf(x * 256.0f) * kBin;
-  const float m = sigmoidf_(a);
-  const float isc = __expf(-fminf(fmaxf(v, -4.5f), 0.0f));
-  const float t = (xq - m) * isc;
-  const float cp = sigmoid_acc(t + kBin * isc);
-  const float cm = sigmoid_acc(t);
-  return -fast_log(cp - cm + 1e-7f);
-}
-__device__ __forceinline__ void nll_dlog_grad(float x, float a, float v, float& ga, float& gv) {
-  const float xq = floorf(x * 256.0f) * kBin;
-  const float m = sigmoidf_(a);
-  const float isc = __expf(-fminf(fmaxf(v, -4.5f), 0.0f));
-  const float t = (xq - m) * isc;
-  const float tp = t + kBin * isc;
-  const float cp = sigmoid_acc(tp);
-  const float cm = sigmoid_acc(t);
-  const float ip = rcp_nr(cp - cm + 1e-7f);
-  const float dp = -cp * (1.0f - cp) * ip;  // d nll / d tp
-  const float dm = cm * (1.0f - cm) * ip;   // d nll / d t
-  ga = (dp + dm) * (-isc) * m * (1.0f - m);
-  const float inside = (v > -4.5f && v < 0.0f) ? 1.0f : 0.0f;  // hardtanh passes no gradient at the clamps
-  gv = (dp * (-tp) + dm * (-t)) * inside;
-}
 
 // ---------------------------------------------------------------------------
 // forward: nll[B] (+ loss[B], elbo[B], block partials of the six sums)
@@ -259,19 +196,6 @@ __global__ __launch_bounds__(kBlock) void elbo_combine_bwd_kernel(
   }
 }
 
-
-// Long rows with few samples: give a row to the whole block so the chip stays full.
-static RowGeom nll_geom(int64_t B, int64_t vecs_per_row, int64_t max_grid) {
-  RowGeom g = row_geom(B, vecs_per_row, max_grid);
-  if (vecs_per_row >= 1024 && g.tiles < 4 * 256) {
-    g.G = kBlock;
-    g.U = 4;
-    g.rows_per_block = 1;
-    g.tiles = B;
-    g.grid = (int)(g.tiles < max_grid ? g.tiles : max_grid);
-  }
-  return g;
-}
 
 template <typename T, int NLL>
 static int nll_fwd_dispatch(const void* x, const void* recon, const void* kld, const void* add, const void* mi,

@@ -34,15 +34,29 @@ def _pack(loss, elbo, means, kl_beta, dtype):
     }
 
 
+def reparameterize_multi(reparameterizer, logits, num_samples, force=False, noise=None):
+    """The reference's "call the reparameterizer N times on the same logits" loops (msg.py:63-69,
+    abstract_vae.py:348-350) -> (z_list, params_list).  One launch when the reparameterizer has a
+    multi-sample kernel (IsotropicGaussian), the plain loop otherwise."""
+    if hasattr(reparameterizer, 'forward_multi'):
+        return reparameterizer.forward_multi(logits, num_samples, force=force, noise=noise)
+    pairs = [reparameterizer(logits, force=force) for _ in range(num_samples)]
+    return [p[0] for p in pairs], [p[1] for p in pairs]
+
+
 def loss_function(recon_x, x, kld, nll_type, kl_beta=1.0, mut_info=None, extra_loss_terms=None, inv_count=None,
                   nll_given=None):
     """The loss dict of abstract_vae.py:377-388 from tensors.  One fused launch (+ a 1-block finalize)
-    when the NLL comes from (x, recon_x); `nll_given` [B] (K > 1 average) uses the combine kernel."""
+    when the NLL comes from (x, recon_x); a LIST of decoder outputs in `recon_x` is the K > 1 case
+    (:347-354: nll averaged over the list, x read once); `nll_given` [B] uses the combine kernel."""
     add = None
     if extra_loss_terms:
         vals = list(extra_loss_terms.values())
         add = vals[0] if len(vals) == 1 else torch.sum(torch.stack(vals, 0), 0)
-    if nll_given is None:
+    if nll_given is None and isinstance(recon_x, (list, tuple)):
+        _, loss, elbo, means = F_.nll_multi_elbo(x, list(recon_x), nll_type, kld=kld, add=add, mi=mut_info,
+                                                 kl_beta=kl_beta, inv_count=inv_count)
+    elif nll_given is None:
         _, loss, elbo, means = F_.nll_elbo(x, recon_x, nll_type, kld=kld, add=add, mi=mut_info, kl_beta=kl_beta,
                                            inv_count=inv_count)
     else:
@@ -102,16 +116,56 @@ class ELBOMixin(object):
 
     def loss_function(self, recon_x, x, params, K=1, **extra_loss_terms):
         nll_type = self.config['nll_type']
-        nll_given = None
         if self.training and K > 1:
-            nll_given = self.nll(x, recon_x, nll_type)
-            for k in range(1, K):
-                z_k, params_k = self.reparameterize(logits=params['logits'], labels=params.get('labels', None))
-                recon_x_i = self.decode(z_k)
-                nll_given = nll_given + self.nll(x, recon_x_i, nll_type)
-            nll_given = nll_given / K
+            # abstract_vae.py:347-354.  The K-1 further draws come from one launch when reparameterize() is
+            # the stock one; each draw is still decoded by its own decode() call (batch-norm decoders would
+            # differ otherwise); the K decoder outputs then go through ONE NLL+ELBO launch.
+            stock = type(self).reparameterize is ELBOMixin.reparameterize
+            if stock and hasattr(self.reparameterizer, 'forward_multi'):
+                z_more, _ = reparameterize_multi(self.reparameterizer, params['logits'], K - 1)
+            else:
+                z_more = [self.reparameterize(logits=params['logits'], labels=params.get('labels', None))[0]
+                          for _ in range(1, K)]
+            recon_x = [recon_x] + [self.decode(z_k) for z_k in z_more]
         kld = self.kld(params)
         mi = self.mut_info(params, x.size(0))
         kl_beta = self.compute_kl_beta([self.config['kl_beta']])[0]
         return loss_function(recon_x, x, kld, nll_type, kl_beta=kl_beta, mut_info=mi,
-                             extra_loss_terms=extra_loss_terms, inv_count=self.inv_count, nll_given=nll_given)
+                             extra_loss_terms=extra_loss_terms, inv_count=self.inv_count)
+
+    def likelihood(self, loader, K=1000):
+        """abstract_vae.py:281-317, quirks included: every sample is expanded to a batch of itself, drawn
+        K // B times through reparameterize() (which returns the MEAN for a Gaussian in eval mode), and the
+        log-sum-exp of the (K // B) * B elbo values is lowered by log(K // B), not by log of their number."""
+        import math
+        with torch.no_grad():
+            likelihood = []
+            for minibatch, labels in loader:
+                dev = 'cuda' if self.config['cuda'] else None
+                minibatch = minibatch.to(dev) if dev else minibatch
+                labels = labels.to(dev) if dev else minibatch
+                z_logits = self.encode(minibatch)
+                batch_size = z_logits.shape[0]
+                for idx in range(batch_size):
+                    z_logits_i = z_logits[idx].expand_as(z_logits).contiguous()
+                    sample_i = minibatch[idx].expand_as(minibatch).contiguous()
+                    label_i = labels[idx].expand_as(labels).contiguous()
+                    elbo = []
+                    for count in range(K // batch_size):
+                        z, params = self.reparameterize(z_logits_i, labels=label_i)
+                        loss_t = self.loss_function(self.decode(z), sample_i, params=params)
+                        elbo.append(loss_t['elbo'])
+                    flat = torch.cat([e.unsqueeze(0) for e in elbo], 0).view([-1])
+                    likelihood.append(torch.logsumexp(flat, dim=0) - math.log(count + 1))
+            return torch.mean(torch.cat([l.unsqueeze(0) for l in likelihood], 0))
+
+
+class MSGMixin(ELBOMixin):
+    """The reparameterize / kld pair of MSGVAE (msg.py:43-69): max_time_steps draws of the same logits, KL
+    from the last parameter set.  The draws are one launch for an IsotropicGaussian."""
+
+    def kld(self, dist_list):
+        return self.reparameterizer.kl(dist_list[-1])
+
+    def reparameterize(self, logits, force=False):
+        return reparameterize_multi(self.reparameterizer, logits, self.config['max_time_steps'], force=force)

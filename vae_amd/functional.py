@@ -765,3 +765,131 @@ def concat_leaves(logits, specs, training, noises, seeds, row0=0):
             n = n.reshape(B, spec[1]).to(logits.dtype).contiguous()
         fixed.append(n)
     return _ConcatLeaves.apply(logits, tuple(specs), bool(training), tuple(fixed), tuple(seeds), int(row0))
+
+
+# --------------------------------------------------------------------------------------
+# Multi-sample forms: S Gaussian draws from one logits read; S-sample NLL + ELBO reading x once
+# (abstract_vae.py:347-354 loss_function K > 1, msg.py:55-69, abstract_vae.py:301-311)
+# --------------------------------------------------------------------------------------
+class _GaussMulti(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, noise, S, eps_tol, seed, offset, row0, mean_scale):
+        ctx.set_materialize_grads(False)
+        dev = check_device(logits, noise)
+        B, L = logits.shape[0], logits.shape[1] // 2
+        z = torch.empty((S, B, L), dtype=logits.dtype, device=dev)
+        logvar = torch.empty((B, L), dtype=logits.dtype, device=dev)
+        kl = torch.empty((B,), dtype=logits.dtype, device=dev)
+        means = torch.zeros((2,), dtype=torch.float32, device=dev)
+        if mean_scale is None:
+            mean_scale = 1.0 / max(B * L, 1)
+        with _Guard(dev):
+            call('vae_gauss_reparam_multi_fwd', ptr(logits), logits.stride(0), ptr(noise), ptr(z), ptr(logvar), ptr(kl),
+                 ptr(means), ptr(workspace(dev)), B, L, S, eps_tol, mean_scale, seed & _MASK64, offset & _MASK64, row0,
+                 dtype_code(logits), stream_ptr(dev))
+        ctx.save_for_backward(logits, noise)
+        ctx.cfg = (S, eps_tol, seed, offset, row0, mean_scale)
+        return z, logvar, kl, means
+
+    @staticmethod
+    def backward(ctx, gz, glogvar, gkl, gmeans):
+        logits, noise = ctx.saved_tensors
+        S, eps_tol, seed, offset, row0, mean_scale = ctx.cfg
+        dev = logits.device
+        B, L = logits.shape[0], logits.shape[1] // 2
+        gz, glogvar, gkl = _dense(gz), _dense(glogvar), _dense(gkl)
+        gmeans = None if gmeans is None else gmeans.contiguous().float()
+        glogits = torch.empty((B, 2 * L), dtype=logits.dtype, device=dev)
+        with _Guard(dev):
+            call('vae_gauss_reparam_multi_bwd', ptr(logits), logits.stride(0), ptr(noise), ptr(gz), ptr(glogvar),
+                 ptr(gkl), ptr(gmeans), ptr(glogits), B, L, S, eps_tol, mean_scale, seed & _MASK64, offset & _MASK64,
+                 row0, dtype_code(logits), stream_ptr(dev))
+        return glogits, None, None, None, None, None, None, None
+
+
+def gauss_reparam_multi(logits, num_samples, noise=None, eps_tol=1e-6, seed=0, offset=0, row0=0, mean_scale=None):
+    """logits [B, 2L] -> (z [S, B, L], logvar [B, L], kl [B], means float32[2]): S training-mode draws
+    from one read of the logits.  `noise` [S, B, L] (or a list of S [B, L] tensors) injects the draws;
+    None: Philox, draw s on call offset `offset + s`."""
+    logits = _rows(logits)
+    B, L = logits.shape[0], logits.shape[1] // 2
+    S = int(num_samples)
+    if noise is not None:
+        if isinstance(noise, (list, tuple)):
+            noise = torch.stack([n.reshape(B, L) for n in noise], 0)
+        noise = noise.reshape(S, B, L).to(logits.dtype).contiguous()
+    return _GaussMulti.apply(logits, noise, S, float(eps_tol), int(seed), int(offset), int(row0), mean_scale)
+
+
+class _NllMultiElbo(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kld, add, mi, nll_code, kl_beta, inv_count, with_elbo, *recons):
+        ctx.set_materialize_grads(False)
+        dev = check_device(x, kld, add, mi, *recons)
+        B, D = x.shape
+        S = len(recons)
+        nll = torch.empty((B,), dtype=x.dtype, device=dev)
+        if with_elbo:
+            loss, elbo = torch.empty_like(nll), torch.empty_like(nll)
+            means = torch.zeros((6,), dtype=torch.float32, device=dev)
+            ws = workspace(dev)
+        else:
+            loss = elbo = means = ws = None
+        with _Guard(dev):
+            call('vae_nll_multi_elbo_fwd', ptr(x), _lib.ptr_array(recons), S, nll_code, ptr(kld), ptr(add), ptr(mi),
+                 kl_beta, inv_count, ptr(nll), ptr(loss), ptr(elbo), ptr(means), ptr(ws), B, D, dtype_code(x),
+                 stream_ptr(dev))
+        ctx.save_for_backward(x, *recons)
+        ctx.cfg = (nll_code, kl_beta, inv_count, kld is not None, add is not None, mi is not None)
+        if not with_elbo:
+            loss, elbo = x.new_empty((0,)), x.new_empty((0,))
+            means = x.new_empty((0,), dtype=torch.float32)
+            ctx.mark_non_differentiable(loss, elbo, means)
+        return nll, loss, elbo, means
+
+    @staticmethod
+    def backward(ctx, gnll, gloss, gelbo, gmeans):
+        x, recons = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        nll_code, kl_beta, inv_count, has_kld, has_add, has_mi = ctx.cfg
+        dev = x.device
+        B, D = x.shape
+        gnll, gloss, gelbo = _dense(gnll), _dense(gloss), _dense(gelbo)
+        if gloss is not None and gloss.numel() == 0:
+            gloss = gelbo = gmeans = None
+        gmeans = None if gmeans is None else gmeans.contiguous().float()
+        grecons = [torch.empty_like(r) for r in recons]
+        gkld = torch.empty((B,), dtype=x.dtype, device=dev) if has_kld and ctx.needs_input_grad[1] else None
+        gadd = torch.empty((B,), dtype=x.dtype, device=dev) if has_add and ctx.needs_input_grad[2] else None
+        gmi = torch.empty((B,), dtype=x.dtype, device=dev) if has_mi and ctx.needs_input_grad[3] else None
+        with _Guard(dev):
+            call('vae_nll_multi_elbo_bwd', ptr(x), _lib.ptr_array(recons), _lib.ptr_array(grecons), len(recons),
+                 nll_code, ptr(gnll), ptr(gloss), ptr(gelbo), ptr(gmeans), kl_beta, inv_count, ptr(gkld), ptr(gadd),
+                 ptr(gmi), B, D, dtype_code(x), stream_ptr(dev))
+        return (None, gkld, gadd, gmi, None, None, None, None) + tuple(grecons)
+
+
+MAX_SAMPLES = 8  # VAE_MAX_SAMPLES in include/vae_amd.h
+
+
+def nll_multi_elbo(x, recons, nll_type, kld=None, add=None, mi=None, kl_beta=1.0, inv_count=None, with_elbo=True):
+    """nll [B] = mean over the S decoder outputs in `recons` of nll(x, recon_s) (abstract_vae.py:344-354), fused
+    with the ELBO combine (:356-388).  Returns (nll, loss, elbo, means[6]); x is read once per launch.
+    More than MAX_SAMPLES outputs: one launch per group, the group NLLs averaged, then the combine kernel."""
+    S = len(recons)
+    flat = [_flat_pixels(x, r, nll_type) for r in recons]
+    code, xf = flat[0][0], flat[0][1]
+    rfs = [f[2] for f in flat]
+    if inv_count is None:
+        inv_count = 1.0 / max(xf.shape[0], 1)
+    if S <= MAX_SAMPLES:
+        return _NllMultiElbo.apply(xf, _dense(kld), _dense(add), _dense(mi), code, float(kl_beta), float(inv_count),
+                                   bool(with_elbo), *rfs)
+    total = None
+    for i in range(0, S, MAX_SAMPLES):
+        grp = rfs[i:i + MAX_SAMPLES]
+        part = _NllMultiElbo.apply(xf, None, None, None, code, 0.0, 0.0, False, *grp)[0] * (len(grp) / S)
+        total = part if total is None else total + part
+    if not with_elbo:
+        return total, None, None, None
+    loss, elbo, means = elbo_combine(total, kld=kld, add=add, mi=mi, kl_beta=kl_beta, inv_count=inv_count)
+    return total, loss, elbo, means

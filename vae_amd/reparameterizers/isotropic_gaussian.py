@@ -91,6 +91,30 @@ class IsotropicGaussian(nn.Module):
         gauss_params['logvar_mean'] = means[1]
         return z, {'z': z, 'logits': logits, 'gaussian': gauss_params}
 
+    def forward_multi(self, logits, num_samples, force=False, noise=None):
+        """`num_samples` forward() calls on the same logits in one launch (the draw loops of msg.py:63-69 and
+        abstract_vae.py:347-351): returns (z_list, params_list) as those loops build them.  mu / logvar / the
+        cached KL are shared by all entries (they do not depend on the draw).  `noise`: [S, B, L] or a list."""
+        S = int(num_samples)
+        if not (self.training or force) or logits.dim() != 2:
+            pairs = [self.forward(logits, force=force, noise=None if noise is None else noise[i]) for i in range(S)]
+            return [p[0] for p in pairs], [p[1] for p in pairs]
+        L = self.output_size
+        assert logits.shape[-1] == 2 * L, "feature_size = {} but requested output_size = {}".format(logits.shape[-1], L)
+        seed, offset = (0, 0) if noise is not None else rng.next_calls(S)
+        z, logvar, kl, means = F_.gauss_reparam_multi(logits, S, noise=noise, eps_tol=EPS_TOL, seed=seed, offset=offset,
+                                                      row0=self.row_offset, mean_scale=self.mean_scale)
+        mu = torch.narrow(logits, -1, 0, L)
+        logvar._vae_amd_kl = (kl, mu)
+        logvar._vae_amd_means = means
+        means = means.to(logits.dtype)
+        z_list, params_list = [], []
+        for i in range(S):
+            g = {'z': z[i], 'mu': mu, 'logvar': logvar, 'mu_mean': means[0], 'logvar_mean': means[1]}
+            z_list.append(z[i])
+            params_list.append({'z': z[i], 'logits': logits, 'gaussian': g})
+        return z_list, params_list
+
     def kl(self, dist_a, prior=None):
         g = dist_a['gaussian']
         if prior is None:

@@ -22,6 +22,13 @@ def next_call():
     return seed, _state['offset']
 
 
+def next_calls(n):
+    """(seed, first offset) for n consecutive draws: draw s uses `offset + s`, exactly what n next_call()s give."""
+    seed, first = next_call()
+    _state['offset'] += n - 1
+    return seed, first
+
+
 def manual_seed(seed):
     """torch.manual_seed + restart of the call counter (re-seeding torch with the SAME value cannot be
     observed from here, so a script that replays a run inside one process calls this instead)."""
