@@ -259,6 +259,26 @@ def loss_function(nll_, kld, kl_beta=1.0, mut_info=None, extra=None):
 
 
 # --------------------------------------------------------------------------------- vrnn
+def gauss_mutual_info(dist, scale):
+    """isotropic_gaussian.py:142-156: KL(N(x params) || N(xhat params)) as a cross-entropy proxy."""
+    a, b = dist['gaussian'], dist['q_z_given_xhat']['gaussian']
+    return scale * torch.sum(D.kl_divergence(D.Normal(a['mu'], a['logvar']), D.Normal(b['mu'], b['logvar'])), -1)
+
+
+def gumbel_mutual_info(dist, scale):
+    """gumbel.py:143-168 (the Monte-Carlo form is the live one): sum p_z (log q(z|xhat) - log q(z|x))."""
+    p_z = F.softmax(dist['discrete']['logits'], dim=-1)
+    cross = torch.sum(p_z * dist['q_z_given_xhat']['discrete']['log_q_z'], -1)
+    ent = -torch.sum(p_z * dist['discrete']['log_q_z'], -1)
+    return scale * (ent + cross)
+
+
+def beta_mutual_info(dist, scale):
+    """beta.py:138-152: KL(Beta(xhat params) || Beta(x params))."""
+    a, b = dist['beta'], dist['q_z_given_xhat']['beta']
+    return scale * torch.sum(D.kl_divergence(D.Beta(b['conc1'], b['conc2']), D.Beta(a['conc1'], a['conc2'])), -1)
+
+
 def nll_multi(x, recon_list, nll_type):
     """abstract_vae.py:344-354: nll of the first decode, += nll of each further draw's decode, / K."""
     out = nll(x, recon_list[0], nll_type)

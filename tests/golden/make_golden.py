@@ -493,6 +493,31 @@ def make_multi(vae, out):
             'dec_weight': dec.weight, 'dec_bias': dec.bias, 'value': val, 'reparam_training': mode})
 
 
+def make_mi(vae, out):
+    """mutual_info() of the leaf reparameterizers (isotropic_gaussian.py:142-156, gumbel.py:143-168,
+    beta.py:138-152): params of x and of the re-encoded reconstruction, both produced by the reference."""
+    R = vae.reparameterizers
+    B = 8
+    torch.manual_seed(1200)
+    for name, cls, size_key, width, scale_key in (('gauss', R.IsotropicGaussian, 'continuous_size', 8, 'continuous_mut_info'),
+                                                  ('gumbel', R.GumbelSoftmax, 'discrete_size', 6, 'discrete_mut_info'),
+                                                  ('beta', R.Beta, 'continuous_size', 8, 'continuous_mut_info')):
+        cfg = base_config(**{size_key: width, scale_key: 0.7})
+        m = cls(cfg)
+        m.train(True)
+        la = torch.randn(B, width, requires_grad=True)
+        lb = torch.randn(B, width, requires_grad=True)
+        if name == 'gauss':   # scales must be positive for Normal-vs-Normal KL to be finite
+            la = torch.cat([la[:, :4], la[:, 4:].abs() + 0.1], -1).detach().requires_grad_(True)
+            lb = torch.cat([lb[:, :4], lb[:, 4:].abs() + 0.1], -1).detach().requires_grad_(True)
+        _, pa = m(la)
+        _, pb = m(lb)
+        mi = m.mutual_info({**pa, 'q_z_given_xhat': pb})
+        ga, gb = torch.autograd.grad((mi * torch.arange(1., B + 1)).sum(), [la, lb])
+        out['mi_%s' % name] = detach_tree({'logits': la, 'logits_xhat': lb, 'scale': 0.7, 'mi': mi,
+                                           'w': torch.arange(1., B + 1), 'grad_logits': ga, 'grad_logits_xhat': gb})
+
+
 def main():
     vae = install_reference()
     out = {}
@@ -506,6 +531,7 @@ def main():
     make_elbo(vae, out)
     make_vrnn(vae, out)
     make_multi(vae, out)
+    make_mi(vae, out)
     groups = {}
     for k, v in out.items():
         groups.setdefault(k.split('_')[0], {})[k] = v

@@ -245,3 +245,22 @@ def test_multi_likelihood(golden, name):
             elbos.append(O.loss_function(nll, O.gauss_kl(p), 1.0)['elbo'])
         vals.append(O.iwae_estimate(elbos, count))
     close(torch.mean(torch.stack(vals)), g['value'])
+
+
+@pytest.mark.parametrize('name', ['gauss', 'gumbel', 'beta'])
+def test_mutual_info(golden, name):
+    g = golden('mi')['mi_' + name]
+    la, lb = g['logits'].clone().requires_grad_(True), g['logits_xhat'].clone().requires_grad_(True)
+    if name == 'gauss':
+        pa, pb = O.gauss_forward(la, None, training=False)[1], O.gauss_forward(lb, None, training=False)[1]
+        mi = O.gauss_mutual_info({**pa, 'q_z_given_xhat': pb}, g['scale'])
+    elif name == 'gumbel':
+        U = torch.rand_like(la)
+        pa, pb = O.gumbel_forward(la, U)[1], O.gumbel_forward(lb, U)[1]
+        mi = O.gumbel_mutual_info({**pa, 'q_z_given_xhat': pb}, g['scale'])
+    else:
+        mi = O.beta_mutual_info({'beta': O.beta_params(la), 'q_z_given_xhat': {'beta': O.beta_params(lb)}}, g['scale'])
+    close(mi, g['mi'])
+    ga, gb = torch.autograd.grad((mi * g['w']).sum(), [la, lb])
+    close(ga, g['grad_logits'], rtol=1e-5, atol=1e-6)
+    close(gb, g['grad_logits_xhat'], rtol=1e-5, atol=1e-6)

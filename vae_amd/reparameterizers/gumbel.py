@@ -62,11 +62,9 @@ class GumbelSoftmax(nn.Module):
                                  row0=self.row_offset)
 
     def mutual_info_monte_carlo(self, params, eps=1e-9):
-        log_q_z_given_x_hat = params['q_z_given_xhat']['discrete']['log_q_z']
-        p_z = F.softmax(params['discrete']['logits'], dim=-1)
-        crossent_loss = torch.sum(p_z * log_q_z_given_x_hat, dim=-1)
-        ent_loss = -torch.sum(p_z * params['discrete']['log_q_z'], dim=-1)
-        return ent_loss + crossent_loss
+        # gumbel.py:153-157: sum p_z log q(z|xhat) - sum p_z log q(z|x) with p_z = softmax(logits) = exp(log_q_z),
+        # i.e. -KL(q(z|x) || q(z|xhat)): one launch of the categorical-KL kernel instead of six torch ops.
+        return -F_.categorical_kl(params['discrete']['log_q_z'], params['q_z_given_xhat']['discrete']['log_q_z'])
 
     def mutual_info(self, params, eps=1e-9):
         return self.config['discrete_mut_info'] * self.mutual_info_monte_carlo(params)
