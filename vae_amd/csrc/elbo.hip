@@ -225,7 +225,7 @@ static int nll_bwd_dispatch(const void* x, const void* recon, const void* gnll, 
                             int64_t D, float kl_beta, float inv_count, hipStream_t stream) {
   constexpr int VN = VecOf<T>::n;
   const bool vec = (D % VN == 0) && aligned16(x) && aligned16(recon) && aligned16(grecon);
-  RowGeom g = nll_geom(B, vec ? D / VN : D, kGridStream);
+  RowGeom g = nll_geom(B, vec ? D / VN : D, kGridStream, true);
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_bwd_kernel<T, VN, NLL, U>), dim3(g.grid), dim3(kBlock), 0, stream,
                                          (const T*)x, (const T*)recon, (const T*)gnll, (const T*)gloss,

@@ -369,7 +369,7 @@ static int nll_multi_bwd_dispatch(const void* x, const PtrPack& rp, const PtrPac
                                   float inv_count, hipStream_t st) {
   constexpr int VN = VecOf<T>::n;
   const bool vec = (D % VN == 0) && aligned16(x) && al;
-  const RowGeom g = nll_geom(B, vec ? D / VN : D, kGridStream);
+  const RowGeom g = nll_geom(B, vec ? D / VN : D, kGridStream, true);
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_multi_bwd_kernel<T, VN, NLL, U>), dim3(g.grid), dim3(kBlock), 0, st,
                                          (const T*)x, rp, gp, S, (const T*)gnll, (const T*)gloss, (const T*)gelbo,

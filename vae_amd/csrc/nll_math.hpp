@@ -76,9 +76,11 @@ __device__ __forceinline__ void nll_dlog_grad(float x, float a, float v, float& 
 }
 
 // Long rows with few samples: give a row to the whole block so the chip stays full.
-inline RowGeom nll_geom(int64_t B, int64_t vecs_per_row, int64_t max_grid) {
+// `long_rows_always`: the store-heavy backward of 3x64x64 rows measured 3-4 points faster block-per-row at any B
+// (fewer concurrent DRAM streams: 5 per block instead of 5 per wave); the forward is not (r01, B=8192).
+inline RowGeom nll_geom(int64_t B, int64_t vecs_per_row, int64_t max_grid, bool long_rows_always = false) {
   RowGeom g = row_geom(B, vecs_per_row, max_grid);
-  if (vecs_per_row >= 1024 && g.tiles < 4 * 256) {
+  if (vecs_per_row >= 1024 && (long_rows_always || g.tiles < 4 * 256)) {
     g.G = kBlock;
     g.U = 4;
     g.rows_per_block = 1;
