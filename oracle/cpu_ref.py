@@ -313,6 +313,17 @@ def vrnn_reparameterize(enc_logits, prior_logits, noise_post, noise_prior, train
     return {'prior': z_pri, 'posterior': z_enc}, {'prior': p_pri, 'posterior': p_enc}
 
 
+def conditioned_reparameterize(logits, labels, mlp_weight, mlp_bias, num_classes, noise_post, noise_prior,
+                               training=True):
+    """conditioned.py:89-135: posterior from the encoder logits; prior from one-hot labels -> dense projector ->
+    sigmoid-clamped scale half (:44-57) -> the same reparameterizer.  Posterior is drawn first."""
+    z_q, p_q = gauss_forward(logits, noise_post, training=training)
+    onehot = F.one_hot(labels, num_classes).type(logits.dtype)
+    prior_logits = clamp_variance(F.linear(onehot, mlp_weight, mlp_bias))
+    _, p_p = gauss_forward(prior_logits, noise_prior, training=training)
+    return z_q, {'labels': labels, 'logits': logits, 'prior': p_p, 'posterior': p_q}
+
+
 def vrnn_kld(dist, use_prior_kl=False):
     """vrnn.py:723-733."""
     prior_kl = gauss_kl(dist['prior']) if use_prior_kl else 0

@@ -518,6 +518,42 @@ def make_mi(vae, out):
                                            'w': torch.arange(1., B + 1), 'grad_logits': ga, 'grad_logits_xhat': gb})
 
 
+def make_conditioned(vae, out):
+    """ClassConditionedPriorVAE.reparameterize / kld / _process_labels unbound on a stub (conditioned.py:44-147)."""
+    C = sys.modules['models.vae.conditioned'].ClassConditionedPriorVAE
+    R = vae.reparameterizers
+    B, L, NC = 8, 4, 5
+    for train in (True, False):
+        for use_prior_kl in (False, True):
+            torch.manual_seed(1300)
+            cfg = base_config(continuous_size=2 * L, output_size=NC, use_prior_kl=use_prior_kl)
+            mlp = nn.Linear(NC, 2 * L)
+
+            class Stub(object):
+                config = cfg
+                reparameterizer = R.IsotropicGaussian(cfg)
+                prior_mlp = mlp
+                _clamp_variance = C._clamp_variance
+                _process_labels = C._process_labels
+
+            st = Stub()
+            st.reparameterizer.train(train)
+            logits = torch.randn(B, 2 * L, requires_grad=True)
+            labels = torch.randint(0, NC, (B,))
+            torch.manual_seed(31)
+            n_post, n_prior = torch.zeros(B, L).normal_(), torch.zeros(B, L).normal_()
+            torch.manual_seed(31)
+            z, params = C.reparameterize(st, logits, labels)
+            kl = C.kld(st, params)
+            w = torch.randn(B, L)
+            g_logits, g_w, g_b = torch.autograd.grad((z * w).sum() + kl.sum(), [logits, mlp.weight, mlp.bias])
+            out['cond_%s_%s' % ('train' if train else 'eval', 'pkl' if use_prior_kl else 'nopkl')] = detach_tree({
+                'logits': logits, 'labels': labels, 'noise_post': n_post, 'noise_prior': n_prior, 'w': w,
+                'mlp_weight': mlp.weight, 'mlp_bias': mlp.bias, 'z': z, 'params': params, 'kld': kl,
+                'grad_logits': g_logits, 'grad_mlp_weight': g_w, 'grad_mlp_bias': g_b, 'training': train,
+                'use_prior_kl': use_prior_kl, 'num_classes': NC})
+
+
 def main():
     vae = install_reference()
     out = {}
@@ -532,6 +568,7 @@ def main():
     make_vrnn(vae, out)
     make_multi(vae, out)
     make_mi(vae, out)
+    make_conditioned(vae, out)
     groups = {}
     for k, v in out.items():
         groups.setdefault(k.split('_')[0], {})[k] = v

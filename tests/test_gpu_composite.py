@@ -304,3 +304,43 @@ def test_vrnn_fused_pair_backward_vs_oracle(B, L, train):
     # kl() against a DIFFERENT prior must not reuse the fused pair value
     other = {'gaussian': {'mu': torch.zeros(B, L, device=DEV), 'logvar': torch.ones(B, L, device=DEV)}}
     close(rep.kl(p1['posterior'], other), O.gauss_kl(p0['posterior']), rtol=1e-5, atol=1e-5 * L)
+
+
+@pytest.mark.parametrize('name', ['cond_train_nopkl', 'cond_train_pkl', 'cond_eval_nopkl', 'cond_eval_pkl'])
+def test_conditioned_prior_golden(golden, name):
+    """ConditionedPriorMixin (one fused pair launch) against ClassConditionedPriorVAE.reparameterize / kld run by
+    the reference: params schema, bit-exact draws, KL and the gradients into the encoder logits and the label
+    projector."""
+    from vae_amd.conditioned import ConditionedPriorMixin
+    from vae_amd.reparameterizers import IsotropicGaussian
+    g = golden('cond')[name]
+    L = g['z'].shape[1]
+
+    class Model(ConditionedPriorMixin, torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.config = cfg(continuous_size=2 * L, output_size=g['num_classes'], use_prior_kl=g['use_prior_kl'])
+            self.reparameterizer = IsotropicGaussian(self.config)
+            self.prior_mlp = torch.nn.Linear(g['num_classes'], 2 * L)
+
+    m = Model().to(DEV)
+    with torch.no_grad():
+        m.prior_mlp.weight.copy_(g['mlp_weight'])
+        m.prior_mlp.bias.copy_(g['mlp_bias'])
+    m.train(g['training'])
+    logits = g['logits'].to(DEV).requires_grad_(True)
+    z, params = m.reparameterize(logits, g['labels'].to(DEV),
+                                 noise=(g['noise_post'].to(DEV), g['noise_prior'].to(DEV)))
+    assert set(params) == set(g['params'])
+    for side in ('prior', 'posterior'):
+        assert set(params[side]) == set(g['params'][side])
+        assert set(params[side]['gaussian']) == set(g['params'][side]['gaussian'])
+    assert torch.equal(z.detach().cpu(), g['z'])
+    close(params['prior']['logits'], g['params']['prior']['logits'], rtol=1e-6, atol=1e-7)
+    close(params['prior']['gaussian']['logvar'], g['params']['prior']['gaussian']['logvar'], rtol=1e-6, atol=1e-7)
+    kl = m.kld(params)
+    close(kl, g['kld'], rtol=1e-5, atol=1e-5)
+    gl, gw, gb = torch.autograd.grad((z * g['w'].to(DEV)).sum() + kl.sum(), [logits, m.prior_mlp.weight, m.prior_mlp.bias])
+    close(gl, g['grad_logits'], rtol=1e-4, atol=1e-5)
+    close(gw, g['grad_mlp_weight'], rtol=1e-4, atol=1e-5)
+    close(gb, g['grad_mlp_bias'], rtol=1e-4, atol=1e-5)

@@ -264,3 +264,20 @@ def test_mutual_info(golden, name):
     ga, gb = torch.autograd.grad((mi * g['w']).sum(), [la, lb])
     close(ga, g['grad_logits'], rtol=1e-5, atol=1e-6)
     close(gb, g['grad_logits_xhat'], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('name', ['cond_train_nopkl', 'cond_train_pkl', 'cond_eval_nopkl', 'cond_eval_pkl'])
+def test_conditioned_prior(golden, name):
+    g = golden('cond')[name]
+    logits = g['logits'].clone().requires_grad_(True)
+    W, b = g['mlp_weight'].clone().requires_grad_(True), g['mlp_bias'].clone().requires_grad_(True)
+    z, params = O.conditioned_reparameterize(logits, g['labels'], W, b, g['num_classes'], g['noise_post'],
+                                             g['noise_prior'], training=g['training'])
+    assert torch.equal(z, g['z'])
+    assert torch.equal(params['prior']['gaussian']['logvar'], g['params']['prior']['gaussian']['logvar'])
+    kl = O.vrnn_kld(params, use_prior_kl=g['use_prior_kl'])      # conditioned.py:137-147 is vrnn.py:723-733
+    assert torch.equal(kl, g['kld'])
+    gl, gw, gb = torch.autograd.grad((z * g['w']).sum() + kl.sum(), [logits, W, b])
+    close(gl, g['grad_logits'])
+    close(gw, g['grad_mlp_weight'], rtol=1e-5, atol=1e-6)
+    close(gb, g['grad_mlp_bias'], rtol=1e-5, atol=1e-6)

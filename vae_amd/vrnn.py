@@ -50,11 +50,11 @@ def reparameterize(reparameterizer, logits_map, config, noise=None):
     return z, params
 
 
-def _reparameterize_fused(rep, logits_map, config, noise):
+def _reparameterize_fused(rep, logits_map, config, noise, force=False):
     enc, pri = logits_map['encoder_logits'], logits_map['prior_logits']
     L = rep.output_size
     assert enc.shape[-1] == 2 * L and pri.shape[-1] == 2 * L
-    training = bool(rep.training)
+    training = bool(rep.training or force)
     seed, offset = (0, 0)
     if training and (noise[0] is None or noise[1] is None):
         seed, offset = rng.next_call()
