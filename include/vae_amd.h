@@ -46,6 +46,7 @@ enum { VAE_NLL_BERNOULLI = 0, VAE_NLL_GAUSSIAN = 1, VAE_NLL_DISC_LOGISTIC = 2 };
  * may be twice as long when K % 8 == 0); unaligned rows (K % 4 != 0) are limited to 1024.   */
 #define VAE_MAX_SOFTMAX_ROW 4096
 #define VAE_MAX_SAMPLES 8   /* decoder outputs one vae_nll_multi_elbo_* call combines */
+#define VAE_MAX_BN_ROW 4096 /* widest BatchNormFlow layer (F % 4 == 0 fp32 / F % 8 == 0 bf16; 1024 otherwise) */
 
 /* ABI version of this header; bumped on any signature change. */
 int vae_abi_version(void);
@@ -206,6 +207,19 @@ int vae_nll_elbo_fwd(const void* x, const void* recon, int nll_type, const void*
 int vae_nll_elbo_bwd(const void* x, const void* recon, int nll_type, const void* gnll, const void* gloss,
                      const void* gelbo, const float* gmeans, float kl_beta, float inv_count, void* grecon, void* gkld,
                      void* gadd, void* gmi, int64_t B, int64_t D, int dtype, vae_stream_t stream);
+/* Forward AND gradient in one pass over x and recon (no counterpart in the reference, whose autograd
+ * re-reads both in its backward): everything vae_nll_elbo_fwd writes, plus
+ *   grecon = grad_scale * inv_count * d nll / d recon   (recon's shape),
+ * i.e. d(loss_mean)/d(recon) for `loss['loss_mean'].backward()` (abstract_vae.py:381 is what the
+ * reference's training loop backpropagates).  loss, elbo, means, workspace are required.
+ * vae_nll_fused_grad_finish then multiplies the n stored values by gmeans[0] + gmeans[1] + gmeans[2]
+ * (the upstream gradients of loss_mean, elbo_mean, nll_mean; a device array of >= 3 floats) --
+ * decided on the device, and a no-op that touches no memory when that sum is exactly 1.
+ * The [B]-sized d kld / d add / d mi come from vae_elbo_combine_bwd.                              */
+int vae_nll_elbo_fused(const void* x, const void* recon, int nll_type, const void* kld, const void* add, const void* mi,
+                       float kl_beta, float inv_count, float grad_scale, void* nll, void* loss, void* elbo, float* means,
+                       float* workspace, void* grecon, int64_t B, int64_t D, int dtype, vae_stream_t stream);
+int vae_nll_fused_grad_finish(void* grecon, const float* gmeans, int64_t n, int dtype, vae_stream_t stream);
 /* The ELBO combine alone, from a given nll [B] (K > 1 Monte-Carlo average,
  * abstract_vae.py:347-354; VRNN per-step dicts, vrnn.py:823-829).               */
 int vae_elbo_combine_fwd(const void* nll, const void* kld, const void* add, const void* mi, float kl_beta,
@@ -245,6 +259,50 @@ int vae_nll_multi_elbo_bwd(const void* x, const void* const* recons, void* const
                            const void* gnll, const void* gloss, const void* gelbo, const float* gmeans, float kl_beta,
                            float inv_count, void* gkld, void* gadd, void* gmi, int64_t B, int64_t D, int dtype,
                            vae_stream_t stream);
+
+/* ---- flow-layer tails (flows/__init__.py; the masked linears / coupling nets stay stock GEMMs) -----
+ * Every tail folds FlowSequential's running `logdets += logdet` (flows/__init__.py:555-557):
+ * logdet_out[b] = (logdet_in ? logdet_in[b] : 0) + this layer's logdet.  logdet_in may alias
+ * logdet_out.  All [B, F] tensors are contiguous unless a stride is given.
+ *
+ * MADE / MADESplit 'direct' (flows/__init__.py:176-178, :121-125): u = (x - m) * exp(-a),
+ * logdet = -sum_f a; pre_exp_tanh applies a = tanh(a) first (:121-122).  m and a are strided views
+ * (MADE: the two halves of one [B, 2F] trunk output; MADESplit: two tensors).                      */
+int vae_made_tail_fwd(const void* x, int64_t stride_x, const void* m, int64_t stride_m, const void* a, int64_t stride_a,
+                      void* u, const void* logdet_in, void* logdet_out, int64_t B, int64_t F, int pre_exp_tanh,
+                      int dtype, vae_stream_t stream);
+/* gu [B, F] / glogdet [B] (each may be NULL) -> gx [B, F] (may be NULL), gm, ga (strided, the raw
+ * pre-tanh a when pre_exp_tanh); uses the saved output u.                                        */
+int vae_made_tail_bwd(const void* u, const void* a, int64_t stride_a, const void* gu, const void* glogdet, void* gx,
+                      void* gm, int64_t stride_gm, void* ga, int64_t stride_ga, int64_t B, int64_t F, int pre_exp_tanh,
+                      int dtype, vae_stream_t stream);
+/* CouplingLayer 'direct' (flows/__init__.py:524-528): log_s = s_raw*(1-mask), t = t_raw*(1-mask),
+ * y = x*exp(log_s) + t, logdet = sum_f log_s.  s_raw NULL = AdditiveCouplingLayer (:458-460:
+ * y = x + t, logdet 0).  mask: F floats on the device (16-byte aligned).                         */
+int vae_coupling_tail_fwd(const void* x, const void* s_raw, const void* t_raw, const float* mask, void* y,
+                          const void* logdet_in, void* logdet_out, int64_t B, int64_t F, int dtype,
+                          vae_stream_t stream);
+/* gx is the direct d y / d x path only (x also feeds the nets through x*mask: stock autograd). */
+int vae_coupling_tail_bwd(const void* x, const void* s_raw, const float* mask, const void* gy, const void* glogdet,
+                          void* gx, void* gs_raw, void* gt_raw, int64_t B, int64_t F, int dtype, vae_stream_t stream);
+/* BatchNormFlow 'direct' (flows/__init__.py:233-257) [+ the Reverse that follows it in a MAF block,
+ * :403-406, when `reverse`: y is stored in reversed column order].
+ *   training: batch mean and var = mean((x - mean)^2) + eps over the B rows of THIS call, from one
+ *   read of x (shifted sums, block partials added in block order in double); else mean_in / var_in
+ *   (the running statistics).  y = exp(log_gamma) * (x - mean) / sqrt(var) + beta;
+ *   logdet = sum_f (log_gamma - 0.5 log var).  log_gamma, beta, mean_in, var_in: F floats.
+ *   stats: caller-owned fp32 scratch of vae_bnflow_stats_floats(F) floats, kept for the backward:
+ *   [0,F) mean | [F,2F) var | [2F,3F) 1/sqrt(var) | [3F,4F) scale | [4F,5F) beta | [5F,6F) logdet terms |
+ *   (backward) [6F,7F) sum_b gy = d beta | [7F,8F) sum_b gy*x_hat | [8F] sum_b glogdet | block partials.
+ *   The caller updates the running statistics from stats[0,2F) (:240-246) and forms
+ *   d log_gamma = exp(log_gamma) * stats[7F..8F) + stats[8F].  F <= VAE_MAX_BN_ROW.               */
+size_t vae_bnflow_stats_floats(int64_t F);
+int vae_bnflow_fwd(const void* x, const float* log_gamma, const float* beta, const float* mean_in, const float* var_in,
+                   float* stats, void* y, const void* logdet_in, void* logdet_out, int64_t B, int64_t F, float eps,
+                   int training, int reverse, int dtype, vae_stream_t stream);
+/* gy [B, F] (in y's column order), glogdet [B] or NULL -> gx [B, F]; fills stats[6F, 8F].       */
+int vae_bnflow_bwd(const void* x, const void* gy, const void* glogdet, float* stats, void* gx, int64_t B, int64_t F,
+                   int training, int reverse, int dtype, vae_stream_t stream);
 
 #ifdef __cplusplus
 }

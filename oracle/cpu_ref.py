@@ -346,6 +346,42 @@ def vrnn_loss(step_losses):
     return agg
 
 
+# --------------------------------------------------------------------------- flow tails
+def made_tail(x, m, a, pre_exp_tanh=False):
+    """flows/__init__.py:121-125 (MADESplit) / :176-178 (MADE), 'direct': -> (u, logdet [B,1])."""
+    if pre_exp_tanh:
+        a = torch.tanh(a)
+    u = (x - m) * torch.exp(-a)
+    return u, -a.sum(-1, keepdim=True)
+
+
+def coupling_tail(x, s_raw, t_raw, mask):
+    """flows/__init__.py:524-528 (s_raw None: the additive layer, :458-460): -> (y, logdet [B,1])."""
+    t = t_raw * (1 - mask)
+    if s_raw is None:
+        return x + t, torch.zeros_like(t).sum(-1, keepdim=True)
+    log_s = s_raw * (1 - mask)
+    return x * torch.exp(log_s) + t, log_s.sum(-1, keepdim=True)
+
+
+def bnflow(x, log_gamma, beta, running_mean, running_var, training=True, eps=1e-5):
+    """flows/__init__.py:233-257 'direct': -> (y, logdet [1], mean, var) (mean/var: what the running
+    statistics are updated with in training, :240-246)."""
+    if training:
+        mean = x.mean(0)
+        var = (x - mean).pow(2).mean(0) + eps
+    else:
+        mean, var = running_mean, running_var
+    x_hat = (x - mean) / var.sqrt()
+    y = torch.exp(log_gamma) * x_hat + beta
+    return y, (log_gamma - 0.5 * torch.log(var)).sum(-1, keepdim=True), mean, var
+
+
+def reverse_columns(x):
+    """flows/__init__.py:403-406."""
+    return x.flip(-1)
+
+
 # ------------------------------------------------------------- the bench's CPU baseline
 def elbo_step(logits, noise, x, recon, nll_type='bernoulli', kl_beta=1.0, backward=True):
     """One SimpleVAE ELBO step of the hot path on the CPU, unfused as in the reference:

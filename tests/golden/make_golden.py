@@ -64,8 +64,12 @@ def install_reference():
 
     layers.EMA = EMA
     for n in ('flatten_layers', 'LinearWarmupWithCosineAnnealing', 'GatedDense', 'SineLinear', 'SNLinear',
-              'BasicDenseBlock', 'Identity', 'View'):
+              'Identity', 'View'):
         setattr(layers, n, None)
+    # stock dense block of the un-vendored helpers: a plain layer_fn(in, out) stands in (the coupling NETS are not
+    # on the path; only what the reference does with their outputs is pinned)
+    layers.BasicDenseBlock = lambda i, o, layer_fn=nn.Linear, normalization_str='none', activation_str='relu': \
+        layer_fn(i, o)
 
     def _absent(*a, **k):
         raise RuntimeError('helpers.distributions is un-vendored: NLL is not part of any fixture')
@@ -554,6 +558,100 @@ def make_conditioned(vae, out):
                 'use_prior_kl': use_prior_kl, 'num_classes': NC})
 
 
+def make_flowtail(vae, out):
+    """flows/__init__.py layers run by the reference itself: MADE, MADESplit (+pre_exp_tanh), BatchNormFlow
+    (train / eval), CouplingLayer, and whole MAF / MAF-split / RealNVP stacks (weights saved)."""
+    FL = sys.modules['models.vae.flows']
+    B, Fd, Hd = 8, 6, 16
+
+    def sd(m):
+        return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    def grads(outs, ws, inputs):
+        obj = sum((o * w).sum() for o, w in zip(outs, ws))
+        return [None if g is None else g.detach().clone() for g in torch.autograd.grad(obj, inputs, allow_unused=True)]
+
+    torch.manual_seed(1400)
+    x = torch.randn(B, Fd, requires_grad=True)
+    wu, wl = torch.randn(B, Fd), torch.randn(B, 1)
+    def tap(mod, store, key):   # record a stock sub-network's output (the tail's input)
+        return mod.register_forward_hook(lambda _m, _i, o: store.__setitem__(key, o.detach().clone()))
+
+    m = FL.MADE(Fd, Hd)
+    taps = {}
+    tap(m.trunk, taps, 'ma')
+    u, ld = m(x)
+    g = grads([u, ld], [wu, wl], [x, m.trunk[3].linear.weight, m.joiner.linear.bias])
+    out['flowtail_made'] = detach_tree({'x': x, 'wu': wu, 'wl': wl, 'state_dict': sd(m), 'u': u, 'logdet': ld, **taps,
+                                        'grad_x': g[0], 'grad_out_weight': g[1], 'grad_joiner_bias': g[2]})
+    for tanh in (False, True):
+        m = FL.MADESplit(Fd, Hd, pre_exp_tanh=tanh)
+        taps = {}
+        tap(m.s_trunk, taps, 'm')
+        tap(m.t_trunk, taps, 'a')
+        u, ld = m(x)
+        g = grads([u, ld], [wu, wl], [x, m.t_trunk[3].linear.weight, m.s_trunk[3].linear.weight])
+        out['flowtail_madesplit_%s' % ('tanh' if tanh else 'plain')] = detach_tree({
+            'x': x, 'wu': wu, 'wl': wl, 'state_dict': sd(m), 'u': u, 'logdet': ld, 'pre_exp_tanh': tanh, **taps,
+            'grad_x': g[0], 'grad_t_out_weight': g[1], 'grad_s_out_weight': g[2]})
+    for train in (True, False):
+        m = FL.BatchNormFlow(Fd, momentum=0.1)
+        with torch.no_grad():
+            m.log_gamma.normal_(0, 0.3)
+            m.beta.normal_()
+            m.running_mean.normal_()
+            m.running_var.uniform_(0.5, 2.0)
+        before = sd(m)
+        m.train(train)
+        xs = (x * 1.7 + 0.4).detach().requires_grad_(True)
+        y, ld = m(xs)
+        g = grads([y, ld.expand(B, 1)], [wu, wl], [xs, m.log_gamma, m.beta])
+        out['flowtail_bn_%s' % ('train' if train else 'eval')] = detach_tree({
+            'x': xs, 'wu': wu, 'wl': wl, 'state_dict_before': before, 'state_dict_after': sd(m), 'y': y,
+            'logdet': ld, 'training': train, 'momentum': 0.1, 'eps': 1e-5, 'grad_x': g[0],
+            'grad_log_gamma': g[1], 'grad_beta': g[2]})
+    mask = (torch.arange(0, Fd) % 2).float()
+    m = FL.CouplingLayer(Fd, Hd, mask)
+    taps = {}
+    tap(m.scale_net, taps, 's_raw')
+    tap(m.translate_net, taps, 't_raw')
+    y, ld = m(x)
+    g = grads([y, ld], [wu, wl], [x, m.scale_net[4].weight, m.translate_net[4].weight])
+    out['flowtail_coupling'] = detach_tree({'x': x, 'wu': wu, 'wl': wl, 'mask': mask, 'state_dict': sd(m), 'y': y, **taps,
+                                            'logdet': ld, 'grad_x': g[0], 'grad_s_out_weight': g[1],
+                                            'grad_t_out_weight': g[2]})
+    m = FL.AdditiveCouplingLayer(Fd, Hd, mask)
+    taps = {}
+    tap(m.net, taps, 't_raw')
+    y, ld = m(x)
+    g = grads([y], [wu], [x])
+    out['flowtail_additive'] = detach_tree({'x': x, 'wu': wu, 'mask': mask, 'state_dict': sd(m), 'y': y, 'logdet': ld, **taps,
+                                            'grad_x': g[0]})
+    # whole stacks, training mode (batch statistics), two blocks each
+    for name, build in (('maf', lambda: FL.build_maf_flow(Fd, Hd, num_blocks=2)),
+                        ('mafsplit', lambda: FL.build_maf_split_flow(Fd, Hd, num_blocks=2)),
+                        ('realnvp', lambda: FL.build_realnvp_flow(Fd, Hd, num_blocks=2))):
+        torch.manual_seed(1410)
+        m = build()
+        for mod in m.modules():
+            if isinstance(mod, FL.BatchNormFlow):
+                with torch.no_grad():
+                    mod.log_gamma.normal_(0, 0.2)
+                    mod.beta.normal_(0, 0.5)
+        before = sd(m)
+        m.train(True)
+        u, ld = m(x)
+        params = [p for p in m.parameters()]
+        g = grads([u, ld], [wu, wl], [x] + params)
+        lp = m.log_probs(x)
+        m.eval()
+        ue, lde = m(x)
+        out['flowtail_stack_%s' % name] = detach_tree({
+            'x': x, 'wu': wu, 'wl': wl, 'state_dict_before': before, 'state_dict_after_train': sd(m), 'u': u,
+            'logdet': ld, 'grad_x': g[0], 'grad_params': g[1:], 'param_names': [k for k, _ in m.named_parameters()],
+            'log_probs_second_train_call': lp, 'u_eval': ue, 'logdet_eval': lde})
+
+
 def main():
     vae = install_reference()
     out = {}
@@ -569,6 +667,7 @@ def main():
     make_multi(vae, out)
     make_mi(vae, out)
     make_conditioned(vae, out)
+    make_flowtail(vae, out)
     groups = {}
     for k, v in out.items():
         groups.setdefault(k.split('_')[0], {})[k] = v

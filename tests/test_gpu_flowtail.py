@@ -1,0 +1,284 @@
+"""GPU parity of the flow-layer tails (csrc/flowtail.hip, vae_amd/flows.py) against the oracle and against
+fixtures produced by the reference's own flows/ layers (tests/golden/flowtail.pt).
+
+Tolerance: rtol 1e-5 fp32 on every output and gradient (exp / tanh / log forms differ from ATen's by ulps),
+bf16 rtol 1e-2.
+"""
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def close(a, b, rtol=1e-5, atol=1e-5):
+    torch.testing.assert_close(a.detach().float().cpu(), b.detach().float().cpu(), rtol=rtol, atol=atol)
+
+
+def load_sd(module, sd):
+    module.load_state_dict({k: v for k, v in sd.items()}, strict=True)
+    return module.to(DEV)
+
+
+# ------------------------------------------------------------------ modules vs the reference's outputs
+def test_made_golden(golden):
+    from vae_amd import flows as FL
+    g = golden('flowtail')['flowtail_made']
+    B, Fd = g['x'].shape
+    m = load_sd(FL.MADE(Fd, 16), g['state_dict'])
+    x = g['x'].to(DEV).requires_grad_(True)
+    u, ld = m(x)
+    assert ld.shape == g['logdet'].shape
+    close(u, g['u'])
+    close(ld, g['logdet'])
+    gr = torch.autograd.grad((u * g['wu'].to(DEV)).sum() + (ld * g['wl'].to(DEV)).sum(),
+                             [x, m.trunk[3].linear.weight, m.joiner.linear.bias])
+    close(gr[0], g['grad_x'])
+    close(gr[1], g['grad_out_weight'])
+    close(gr[2], g['grad_joiner_bias'])
+
+
+@pytest.mark.parametrize('name', ['flowtail_madesplit_plain', 'flowtail_madesplit_tanh'])
+def test_madesplit_golden(golden, name):
+    from vae_amd import flows as FL
+    g = golden('flowtail')[name]
+    B, Fd = g['x'].shape
+    m = load_sd(FL.MADESplit(Fd, 16, pre_exp_tanh=g['pre_exp_tanh']), g['state_dict'])
+    x = g['x'].to(DEV).requires_grad_(True)
+    u, ld = m(x)
+    close(u, g['u'])
+    close(ld, g['logdet'])
+    gr = torch.autograd.grad((u * g['wu'].to(DEV)).sum() + (ld * g['wl'].to(DEV)).sum(),
+                             [x, m.t_trunk[3].linear.weight, m.s_trunk[3].linear.weight])
+    close(gr[0], g['grad_x'])
+    close(gr[1], g['grad_t_out_weight'])
+    close(gr[2], g['grad_s_out_weight'])
+
+
+@pytest.mark.parametrize('name', ['flowtail_bn_train', 'flowtail_bn_eval'])
+def test_bn_golden(golden, name):
+    from vae_amd import flows as FL
+    g = golden('flowtail')[name]
+    B, Fd = g['x'].shape
+    m = load_sd(FL.BatchNormFlow(Fd, momentum=g['momentum'], eps=g['eps']), g['state_dict_before'])
+    m.train(g['training'])
+    x = g['x'].to(DEV).requires_grad_(True)
+    y, ld = m(x)
+    assert ld.shape == g['logdet'].shape
+    close(y, g['y'])
+    close(ld, g['logdet'])
+    gr = torch.autograd.grad((y * g['wu'].to(DEV)).sum() + (ld.expand(B, 1) * g['wl'].to(DEV)).sum(),
+                             [x, m.log_gamma, m.beta])
+    close(gr[0], g['grad_x'])
+    close(gr[1], g['grad_log_gamma'])
+    close(gr[2], g['grad_beta'])
+    for k in ('running_mean', 'running_var'):
+        close(getattr(m, k), g['state_dict_after'][k], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('name', ['flowtail_coupling', 'flowtail_additive'])
+def test_coupling_golden(golden, name):
+    from vae_amd import flows as FL
+    g = golden('flowtail')[name]
+    B, Fd = g['x'].shape
+    cls = FL.CouplingLayer if name.endswith('coupling') else FL.AdditiveCouplingLayer
+    m = load_sd(cls(Fd, 16, g['mask'].to(DEV)), g['state_dict'])
+    x = g['x'].to(DEV).requires_grad_(True)
+    y, ld = m(x)
+    close(y, g['y'])
+    close(ld, g['logdet'])
+    (gx,) = torch.autograd.grad((y * g['wu'].to(DEV)).sum() + (ld * g.get('wl', torch.zeros(B, 1)).to(DEV)).sum(), x,
+                                retain_graph=True)
+    close(gx, g['grad_x'])
+    if 'grad_s_out_weight' in g:
+        gs, gt = torch.autograd.grad((y * g['wu'].to(DEV)).sum() + (ld * g['wl'].to(DEV)).sum(),
+                                     [m.scale_net[4].weight, m.translate_net[4].weight])
+        close(gs, g['grad_s_out_weight'])
+        close(gt, g['grad_t_out_weight'])
+
+
+@pytest.mark.parametrize('name', ['maf', 'mafsplit', 'realnvp'])
+def test_stack_golden(golden, name):
+    """Two-block MAF / MAF-split / RealNVP stacks built by the reference: output, accumulated logdet, every
+    parameter gradient, running statistics, log_probs and the eval-mode pass."""
+    from vae_amd import flows as FL
+    g = golden('flowtail')['flowtail_stack_' + name]
+    B, Fd = g['x'].shape
+    build = {'maf': lambda: FL.build_maf_flow(Fd, 16, num_blocks=2),
+             'mafsplit': lambda: FL.build_maf_split_flow(Fd, 16, num_blocks=2),
+             'realnvp': lambda: FL.build_realnvp_flow(Fd, 16, num_blocks=2, cuda=True)}[name]
+    m = build()
+    assert [k for k, _ in m.named_parameters()] == g['param_names']
+    load_sd(m, g['state_dict_before'])
+    m.train(True)
+    x = g['x'].to(DEV).requires_grad_(True)
+    u, ld = m(x)
+    assert ld.shape == g['logdet'].shape
+    close(u, g['u'], rtol=1e-5, atol=2e-5)
+    close(ld, g['logdet'], rtol=1e-5, atol=2e-5)
+    params = [p for p in m.parameters()]
+    gr = torch.autograd.grad((u * g['wu'].to(DEV)).sum() + (ld * g['wl'].to(DEV)).sum(), [x] + params,
+                             allow_unused=True)
+    close(gr[0], g['grad_x'], rtol=1e-4, atol=1e-4)
+    for got, want, pn in zip(gr[1:], g['grad_params'], g['param_names']):
+        if want is None:
+            assert got is None or float(got.abs().max()) == 0.0, pn
+        else:
+            close(got, want, rtol=1e-4, atol=1e-4)
+    close(m.log_probs(x), g['log_probs_second_train_call'], rtol=1e-5, atol=1e-4)
+    sd = m.state_dict()
+    for k, v in g['state_dict_after_train'].items():
+        if 'running' in k:
+            close(sd[k], v, rtol=1e-5, atol=1e-6)
+    m.eval()
+    ue, lde = m(x)
+    close(ue, g['u_eval'], rtol=1e-5, atol=2e-5)
+    close(lde, g['logdet_eval'], rtol=1e-5, atol=2e-5)
+
+
+# ------------------------------------------------------------------ kernels vs the oracle, many shapes
+@pytest.mark.parametrize('B,Fd', [(1, 1), (5, 3), (33, 64), (257, 100), (1024, 512), (300, 1028), (64, 4096)])
+@pytest.mark.parametrize('tanh', [False, True])
+def test_made_tail_vs_oracle(B, Fd, tanh):
+    from vae_amd import functional as F_
+    torch.manual_seed(B + Fd)
+    x, ma, ld0 = torch.randn(B, Fd), torch.randn(B, 2 * Fd), torch.randn(B)
+    wu, wl = torch.randn(B, Fd), torch.randn(B)
+    xc, mac, lc = [t.clone().requires_grad_(True) for t in (x, ma, ld0)]
+    u0, l0 = O.made_tail(xc, mac[:, :Fd], mac[:, Fd:], pre_exp_tanh=tanh)
+    l0 = lc + l0.squeeze(-1)
+    g0 = torch.autograd.grad((u0 * wu).sum() + (l0 * wl).sum(), [xc, mac, lc])
+    xd, mad, ld = [t.to(DEV).requires_grad_(True) for t in (x, ma, ld0)]
+    if tanh:   # the split form: two separate tensors
+        md, ad = mad[:, :Fd].contiguous(), mad[:, Fd:].contiguous()
+        u1, l1 = F_.made_tail(xd, md, ad, logdet_in=ld, pre_exp_tanh=True)
+    else:      # the packed form
+        u1, l1 = F_.made_tail(xd, mad, None, logdet_in=ld)
+    close(u1, u0)
+    close(l1, l0, rtol=1e-5, atol=1e-5 * max(Fd, 1) ** 0.5)
+    g1 = torch.autograd.grad((u1 * wu.to(DEV)).sum() + (l1 * wl.to(DEV)).sum(), [xd, mad, ld])
+    for a, b in zip(g1, g0):
+        close(a, b)
+
+
+@pytest.mark.parametrize('B,Fd', [(1, 2), (7, 6), (129, 64), (512, 500), (1000, 1024)])
+@pytest.mark.parametrize('additive', [False, True])
+def test_coupling_tail_vs_oracle(B, Fd, additive):
+    from vae_amd import functional as F_
+    torch.manual_seed(B * 3 + Fd)
+    x, s, t, ld0 = torch.randn(B, Fd), torch.randn(B, Fd) * 0.5, torch.randn(B, Fd), torch.randn(B)
+    mask = (torch.arange(Fd) % 2).float()
+    wu, wl = torch.randn(B, Fd), torch.randn(B)
+    xc, sc, tc, lc = [v.clone().requires_grad_(True) for v in (x, s, t, ld0)]
+    y0, l0 = O.coupling_tail(xc, None if additive else sc, tc, mask)
+    l0 = lc + l0.squeeze(-1)
+    ins0 = [xc, tc, lc] if additive else [xc, sc, tc, lc]
+    g0 = torch.autograd.grad((y0 * wu).sum() + (l0 * wl).sum(), ins0)
+    xd, sd, td, ld = [v.to(DEV).requires_grad_(True) for v in (x, s, t, ld0)]
+    y1, l1 = F_.coupling_tail(xd, None if additive else sd, td, mask.to(DEV), logdet_in=ld)
+    close(y1, y0)
+    close(l1, l0, rtol=1e-5, atol=1e-5 * Fd ** 0.5)
+    ins1 = [xd, td, ld] if additive else [xd, sd, td, ld]
+    g1 = torch.autograd.grad((y1 * wu.to(DEV)).sum() + (l1 * wl.to(DEV)).sum(), ins1)
+    for a, b in zip(g1, g0):
+        close(a, b)
+
+
+@pytest.mark.parametrize('B,Fd', [(2, 1), (8, 6), (100, 64), (1000, 100), (4096, 512), (777, 1024), (300, 1022),
+                                  (513, 2048), (260, 4096)])
+@pytest.mark.parametrize('train', [True, False])
+@pytest.mark.parametrize('reverse', [False, True])
+def test_bnflow_vs_oracle(B, Fd, train, reverse):
+    """Batch statistics with a common offset several std wide (|mean| up to ~20, std 0.5..2: the shifted sums must
+    not cancel),
+    normalise, logdet, the fused Reverse, and the full backward (through the batch statistics)."""
+    from vae_amd import functional as F_
+    torch.manual_seed(B + 7 * Fd)
+    x = torch.randn(B, Fd) * (0.5 + 1.5 * torch.rand(Fd)) + 5.0 * torch.randn(Fd)
+    lg, beta = torch.randn(Fd) * 0.3, torch.randn(Fd)
+    rm, rv = 5.0 * torch.randn(Fd), 0.5 + torch.rand(Fd)
+    ld0 = torch.randn(B)
+    wu, wl = torch.randn(B, Fd), torch.randn(B)
+    xc, lgc, bc, lc = [v.clone().requires_grad_(True) for v in (x, lg, beta, ld0)]
+    y0, l0, mean0, var0 = O.bnflow(xc, lgc, bc, rm, rv, training=train)
+    if reverse:
+        y0 = O.reverse_columns(y0)
+    l0 = lc + l0
+    g0 = torch.autograd.grad((y0 * wu).sum() + (l0 * wl).sum(), [xc, lgc, bc, lc])
+    xd, lgd, bd, ld = [v.to(DEV).requires_grad_(True) for v in (x, lg, beta, ld0)]
+    y1, l1, mean1, var1 = F_.bnflow(xd, lgd, bd, rm.to(DEV), rv.to(DEV), logdet_in=ld, training=train, reverse=reverse)
+    close(mean1, mean0, rtol=1e-6, atol=1e-5)
+    close(var1, var0, rtol=2e-5, atol=1e-7)
+    # an ulp of the fp32 batch mean (|mean| ~ 20: 2e-6) shows up in y divided by the std
+    close(y1, y0, rtol=1e-5, atol=3e-5)
+    close(l1, l0, rtol=1e-5, atol=1e-5 * Fd ** 0.5)
+    g1 = torch.autograd.grad((y1 * wu.to(DEV)).sum() + (l1 * wl.to(DEV)).sum(), [xd, lgd, bd, ld])
+    scale = float(g0[0].abs().max())
+    close(g1[0], g0[0], rtol=1e-4, atol=1e-4 * max(scale, 1.0))
+    close(g1[1], g0[1], rtol=1e-4, atol=1e-4 * max(float(g0[1].abs().max()), 1.0))
+    close(g1[2], g0[2], rtol=1e-4, atol=1e-4 * max(float(g0[2].abs().max()), 1.0))
+    close(g1[3], g0[3])
+
+
+def test_flowtail_bf16():
+    from vae_amd import functional as F_
+    torch.manual_seed(5)
+    B, Fd = 256, 128
+    x, ma = torch.randn(B, Fd).bfloat16(), torch.randn(B, 2 * Fd).bfloat16()
+    u0, l0 = O.made_tail(x.float(), ma[:, :Fd].float(), ma[:, Fd:].float())
+    u1, l1 = F_.made_tail(x.to(DEV), ma.to(DEV))
+    assert u1.dtype == torch.bfloat16
+    close(u1, u0, rtol=1e-2, atol=1e-2)
+    close(l1, l0.squeeze(-1), rtol=1e-2, atol=0.2)
+    lg, beta = torch.randn(Fd) * 0.3, torch.randn(Fd)
+    y0, ld0, _, _ = O.bnflow(x.float(), lg, beta, None, None, training=True)
+    y1, ld1, _, _ = F_.bnflow(x.to(DEV), lg.to(DEV), beta.to(DEV), training=True, reverse=True)
+    close(y1, O.reverse_columns(y0), rtol=2e-2, atol=2e-2)
+    close(ld1, ld0.expand(B), rtol=1e-2, atol=0.2)
+
+
+def test_flowtail_empty_and_limits():
+    from vae_amd import functional as F_
+    u, ld = F_.made_tail(torch.zeros(0, 8, device=DEV), torch.zeros(0, 16, device=DEV))
+    assert u.shape == (0, 8) and ld.shape == (0,)
+    with pytest.raises(RuntimeError):   # wider than VAE_MAX_BN_ROW
+        F_.bnflow(torch.zeros(4, 8192, device=DEV), torch.zeros(8192, device=DEV), torch.zeros(8192, device=DEV))
+
+
+def test_flow_reparameterizer_with_kernel_backed_maf():
+    """FlowReparameterizer over a vae_amd.flows MAF stack: forward + the flow 'KL' + backward run end to end
+    (the reference's reparameterizers/flow.py:80-92 + :67-78 with flows.build_maf_flow)."""
+    from vae_amd import flows as FL
+    from vae_amd.reparameterizers import FlowReparameterizer
+    torch.manual_seed(9)
+    B, Fd = 512, 64
+    flow = FL.build_maf_flow(Fd, 128, num_blocks=3).to(DEV)
+    m = FlowReparameterizer({'continuous_size': Fd, 'flow_module': flow})
+    m.train()
+    x = torch.randn(B, Fd, device=DEV, requires_grad=True)
+    z, params = m(x)
+    kl = m.kl(params)
+    assert z.shape == (B, Fd) and kl.shape == (B,) and params['logdet'].shape == (B, 1)
+    # the same stack, layer by layer, in plain torch on the CPU copy of the weights
+    cpu = {k: v.detach().cpu() for k, v in flow.state_dict().items()}
+    h, ld = x.detach().cpu(), torch.zeros(B, 1)
+    for i in range(3):
+        p = '%d.' % (3 * i)
+        w = lambda n: cpu[p + n]
+        a1 = torch.nn.functional.linear(h, w('joiner.linear.weight') * w('joiner.mask'), w('joiner.linear.bias'))
+        a2 = torch.nn.functional.linear(torch.relu(a1), w('trunk.1.linear.weight') * w('trunk.1.mask'),
+                                        w('trunk.1.linear.bias'))
+        ma = torch.nn.functional.linear(torch.relu(a2), w('trunk.3.linear.weight') * w('trunk.3.mask'),
+                                        w('trunk.3.linear.bias'))
+        h, l1 = O.made_tail(h, ma[:, :Fd], ma[:, Fd:])
+        q = '%d.' % (3 * i + 1)
+        h, l2, _, _ = O.bnflow(h, cpu[q + 'log_gamma'], cpu[q + 'beta'], None, None, training=True)
+        h = O.reverse_columns(h)
+        ld = ld + l1 + l2
+    close(z, h, rtol=1e-4, atol=1e-4)
+    close(params['logdet'], ld, rtol=1e-4, atol=1e-3)
+    close(kl, O.flow_kl({'recon_x': h, 'logdet': ld}), rtol=1e-4, atol=1e-3)
+    (gx,) = torch.autograd.grad(kl.sum() + z.sum(), x)
+    assert bool(torch.isfinite(gx).all())

@@ -281,3 +281,44 @@ def test_conditioned_prior(golden, name):
     close(gl, g['grad_logits'])
     close(gw, g['grad_mlp_weight'], rtol=1e-5, atol=1e-6)
     close(gb, g['grad_mlp_bias'], rtol=1e-5, atol=1e-6)
+
+
+# ---- flow-layer tails (flows/__init__.py), tail inputs recorded from the reference's own sub-networks ----
+def test_flowtail_made(golden):
+    g = golden('flowtail')['flowtail_made']
+    Fd = g['x'].shape[1]
+    u, ld = O.made_tail(g['x'], g['ma'][:, :Fd], g['ma'][:, Fd:])
+    assert torch.equal(u, g['u']) and torch.equal(ld, g['logdet'])
+
+
+@pytest.mark.parametrize('name', ['flowtail_madesplit_plain', 'flowtail_madesplit_tanh'])
+def test_flowtail_madesplit(golden, name):
+    g = golden('flowtail')[name]
+    u, ld = O.made_tail(g['x'], g['m'], g['a'], pre_exp_tanh=g['pre_exp_tanh'])
+    assert torch.equal(u, g['u']) and torch.equal(ld, g['logdet'])
+
+
+@pytest.mark.parametrize('name', ['flowtail_coupling', 'flowtail_additive'])
+def test_flowtail_coupling(golden, name):
+    g = golden('flowtail')[name]
+    y, ld = O.coupling_tail(g['x'], g.get('s_raw'), g['t_raw'], g['mask'])
+    assert torch.equal(y, g['y']) and torch.equal(ld, g['logdet'])
+
+
+@pytest.mark.parametrize('name', ['flowtail_bn_train', 'flowtail_bn_eval'])
+def test_flowtail_bn(golden, name):
+    g = golden('flowtail')[name]
+    sd = g['state_dict_before']
+    x = g['x'].clone().requires_grad_(True)
+    lg, beta = sd['log_gamma'].clone().requires_grad_(True), sd['beta'].clone().requires_grad_(True)
+    y, ld, mean, var = O.bnflow(x, lg, beta, sd['running_mean'], sd['running_var'], training=g['training'],
+                                eps=g['eps'])
+    assert torch.equal(y, g['y']) and torch.equal(ld, g['logdet'])
+    gx, glg, gb = torch.autograd.grad((y * g['wu']).sum() + (ld.expand(x.shape[0], 1) * g['wl']).sum(), [x, lg, beta])
+    close(gx, g['grad_x'])
+    close(glg, g['grad_log_gamma'])
+    close(gb, g['grad_beta'])
+    if g['training']:   # running statistics: flows/__init__.py:240-246
+        mom = g['momentum']
+        close(sd['running_mean'] * mom + mean.detach() * (1 - mom), g['state_dict_after']['running_mean'])
+        close(sd['running_var'] * mom + var.detach() * (1 - mom), g['state_dict_after']['running_var'])

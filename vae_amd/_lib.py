@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the CDLL below, see module 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VAE_AMD_LIB') or os.path.join(_HERE, 'libvae_amd.so')  # env override: tuning builds only
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 VAE_OK, VAE_ERR_ARG, VAE_ERR_LAUNCH = 0, 1, 2
 VAE_F32, VAE_BF16 = 0, 1
@@ -53,6 +53,8 @@ SIGNATURES = {
     'vae_flow_kl_bwd': [_p, _p, _p, _p, _i64, _i64, _f, _i, _p],
     'vae_nll_elbo_fwd': [_p, _p, _i, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
     'vae_nll_elbo_bwd': [_p, _p, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i64, _i, _p],
+    'vae_nll_elbo_fused': [_p, _p, _i, _p, _p, _p, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
+    'vae_nll_fused_grad_finish': [_p, _p, _i64, _i, _p],
     'vae_elbo_combine_fwd': [_p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i, _p],
     'vae_elbo_combine_bwd': [_p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i, _p],
     'vae_gauss_reparam_multi_fwd': [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _f, _f, _u64, _u64, _i64, _i, _p],
@@ -60,6 +62,13 @@ SIGNATURES = {
                                     _p],
     'vae_nll_multi_elbo_fwd': [_p, _pp, _i64, _i, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
     'vae_nll_multi_elbo_bwd': [_p, _pp, _pp, _i64, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i64, _i64, _i, _p],
+    'vae_made_tail_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _i, _p],
+    'vae_made_tail_bwd': [_p, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i, _i, _p],
+    'vae_coupling_tail_fwd': [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
+    'vae_coupling_tail_bwd': [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
+    'vae_bnflow_stats_floats': [_i64],
+    'vae_bnflow_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f, _i, _i, _i, _p],
+    'vae_bnflow_bwd': [_p, _p, _p, _p, _p, _i64, _i64, _i, _i, _i, _p],
 }
 
 _lib = None
@@ -79,7 +88,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_size_t if name == 'vae_workspace_bytes' else ctypes.c_int
+        fn.restype = ctypes.c_size_t if name in ('vae_workspace_bytes', 'vae_bnflow_stats_floats') else ctypes.c_int
     if lib.vae_abi_version() != ABI_VERSION:
         raise RuntimeError("vae_amd: libvae_amd.so has ABI %d, the binding expects %d; rebuild"
                            % (lib.vae_abi_version(), ABI_VERSION))

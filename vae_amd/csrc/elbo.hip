@@ -197,6 +197,145 @@ __global__ __launch_bounds__(kBlock) void elbo_combine_bwd_kernel(
 }
 
 
+// ---------------------------------------------------------------------------
+// forward + gradient in ONE pass over x and recon (no reference counterpart: the reference's
+// autograd re-reads both tensors in its backward).  Besides everything the forward kernel
+// writes, grecon = cscale * d nll / d recon is stored, cscale = inv_count * grad_scale: exactly
+// d(loss_mean)/d(recon) when the step backpropagates loss_mean alone (loss['loss_mean'].backward(),
+// the reference's training loop).  The step then moves 12D (20D for the variance NLLs) bytes per
+// sample through HBM instead of 8D + 12D (12D + 20D).  vae_nll_fused_grad_finish rescales the
+// stored gradient on the device when the upstream gradient turns out not to be 1.
+// ---------------------------------------------------------------------------
+template <typename T, int V, int NLL, int U>
+__global__ __launch_bounds__(kBlock) void nll_elbo_fused_kernel(
+    const T* __restrict__ x, const T* __restrict__ recon, const T* __restrict__ kld, const T* __restrict__ add,
+    const T* __restrict__ mi, T* __restrict__ nll_out, T* __restrict__ loss, T* __restrict__ elbo,
+    float* __restrict__ ws, float inv_count, float* __restrict__ means, T* __restrict__ grecon, float cscale,
+    int64_t B, int D, float kl_beta, int G, int64_t tiles) {
+  const int rpb = kBlock / G;
+  const int sub = threadIdx.x % G;
+  const int rloc = threadIdx.x / G;
+  const int nvec = D / V;
+  const int64_t rstride = (NLL == VAE_NLL_BERNOULLI) ? (int64_t)D : 2 * (int64_t)D;
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t row = t * rpb + rloc;
+    float s = 0.f;
+    if (row < B) {
+      const T* xr = x + row * D;
+      const T* rr = recon + row * rstride;
+      T* gr = grecon + row * rstride;
+      for (int j0 = sub; j0 < nvec; j0 += G * U) {
+        float xv[U][V], a[U][V], b[U][V];
+        load_chunk<T, V, U, kNtNllFwd>(xr, j0, G, nvec, xv);
+        load_chunk<T, V, U, kNtNllFwd>(rr, j0, G, nvec, a);
+        if constexpr (NLL != VAE_NLL_BERNOULLI) load_chunk<T, V, U, kNtNllFwd>(rr + D, j0, G, nvec, b);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = j0 + u * G;
+          if (j < nvec) {
+            float ga[V], gb[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+              if constexpr (NLL == VAE_NLL_BERNOULLI) {
+                // one exp serves both: softplus(-|l|) for the value, sigmoid(l) for the gradient
+                const float l = a[u][i];
+                const float e = fast_exp(-fabsf(l));
+                const float r = fast_rcp(1.0f + e);
+                s += fmaxf(l, 0.0f) - l * xv[u][i] + fast_log(1.0f + e);
+                ga[i] = cscale * ((l >= 0.0f ? r : e * r) - xv[u][i]);
+              }
+              if constexpr (NLL == VAE_NLL_GAUSSIAN) {
+                s += nll_gauss(xv[u][i], a[u][i], b[u][i]);
+                nll_gauss_grad(xv[u][i], a[u][i], b[u][i], ga[i], gb[i]);
+                ga[i] *= cscale; gb[i] *= cscale;
+              }
+              if constexpr (NLL == VAE_NLL_DISC_LOGISTIC) {
+                s += nll_dlog(xv[u][i], a[u][i], b[u][i]);
+                nll_dlog_grad(xv[u][i], a[u][i], b[u][i], ga[i], gb[i]);
+                ga[i] *= cscale; gb[i] *= cscale;
+              }
+            }
+            store_vec<T, V>(gr + (int64_t)j * V, ga);
+            if constexpr (NLL != VAE_NLL_BERNOULLI) store_vec<T, V>(gr + D + (int64_t)j * V, gb);
+          }
+        }
+      }
+    }
+    s = row_sum(s, G);
+    if (row < B && sub == 0) {
+      const float n = to_f32(from_f32<T>(s));
+      nll_out[row] = from_f32<T>(n);
+      const float k = kld ? to_f32(kld[row]) : 0.f;
+      const float ad = add ? to_f32(add[row]) : 0.f;
+      const float m = mi ? to_f32(mi[row]) : 0.f;
+      const float e = to_f32(from_f32<T>(n + k));
+      const float l = to_f32(from_f32<T>((n + ad + kl_beta * k) - m));
+      loss[row] = from_f32<T>(l);
+      elbo[row] = from_f32<T>(e);
+      acc[0] += l; acc[1] += e; acc[2] += n; acc[3] += k; acc[4] += ad; acc[5] += m;
+    }
+  }
+  grid_reduce<6>(acc, ws, inv_count, means);
+}
+
+// buf *= (gmeans[0] + gmeans[1] + gmeans[2]) unless that sum is exactly 1 (then no memory is touched):
+// the stored d(loss_mean)/d(recon) becomes the gradient for any upstream weights on loss_mean, elbo_mean, nll_mean.
+template <typename T, int V>
+__global__ __launch_bounds__(kBlock) void scale_by_mean_grads_kernel(T* __restrict__ buf, const float* __restrict__ gmeans,
+                                                                     int64_t nvec_total) {
+  const float c = gmeans[0] + gmeans[1] + gmeans[2];
+  if (c == 1.0f) return;
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < nvec_total; j += (int64_t)gridDim.x * kBlock) {
+    float v[V];
+    load_vec<T, V, false>(buf + j * V, v);
+#pragma unroll
+    for (int i = 0; i < V; ++i) v[i] *= c;
+    store_vec<T, V>(buf + j * V, v);
+  }
+}
+
+template <typename T, int NLL>
+static int nll_fused_dispatch(const void* x, const void* recon, const void* kld, const void* add, const void* mi,
+                              void* nll, void* loss, void* elbo, float* means, float* workspace, void* grecon,
+                              float cscale, int64_t B, int64_t D, float kl_beta, float inv_count, hipStream_t stream) {
+  constexpr int VN = VecOf<T>::n;
+  const bool vec = (D % VN == 0) && aligned16(x) && aligned16(recon) && aligned16(grecon);
+  const RowGeom g = nll_geom(B, vec ? D / VN : D, kGridReduce, true);
+  if (vec) {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_fused_kernel<T, VN, NLL, U>), dim3(g.grid), dim3(kBlock), 0, stream,
+                                         (const T*)x, (const T*)recon, (const T*)kld, (const T*)add, (const T*)mi,
+                                         (T*)nll, (T*)loss, (T*)elbo, workspace, inv_count, means, (T*)grecon, cscale, B,
+                                         (int)D, kl_beta, g.G, g.tiles));
+  } else {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_fused_kernel<T, 1, NLL, U>), dim3(g.grid), dim3(kBlock), 0, stream,
+                                         (const T*)x, (const T*)recon, (const T*)kld, (const T*)add, (const T*)mi,
+                                         (T*)nll, (T*)loss, (T*)elbo, workspace, inv_count, means, (T*)grecon, cscale, B,
+                                         (int)D, kl_beta, g.G, g.tiles));
+  }
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+template <typename T>
+static int nll_fused_type(int nll_type, const void* x, const void* recon, const void* kld, const void* add,
+                          const void* mi, void* nll, void* loss, void* elbo, float* means, float* workspace,
+                          void* grecon, float cscale, int64_t B, int64_t D, float kl_beta, float inv_count,
+                          hipStream_t st) {
+  switch (nll_type) {
+    case VAE_NLL_BERNOULLI:
+      return nll_fused_dispatch<T, VAE_NLL_BERNOULLI>(x, recon, kld, add, mi, nll, loss, elbo, means, workspace, grecon,
+                                                      cscale, B, D, kl_beta, inv_count, st);
+    case VAE_NLL_GAUSSIAN:
+      return nll_fused_dispatch<T, VAE_NLL_GAUSSIAN>(x, recon, kld, add, mi, nll, loss, elbo, means, workspace, grecon,
+                                                     cscale, B, D, kl_beta, inv_count, st);
+    case VAE_NLL_DISC_LOGISTIC:
+      return nll_fused_dispatch<T, VAE_NLL_DISC_LOGISTIC>(x, recon, kld, add, mi, nll, loss, elbo, means, workspace,
+                                                          grecon, cscale, B, D, kl_beta, inv_count, st);
+  }
+  return VAE_ERR_ARG;
+}
+
 template <typename T, int NLL>
 static int nll_fwd_dispatch(const void* x, const void* recon, const void* kld, const void* add, const void* mi,
                             void* nll, void* loss, void* elbo, float* means, float* workspace, int64_t B, int64_t D,
@@ -314,6 +453,43 @@ int vae_nll_elbo_bwd(const void* x, const void* recon, int nll_type, const void*
     return nll_bwd_type<bf16_t>(nll_type, x, recon, gnll, gloss, gelbo, gmeans, grecon, gkld, gadd, gmi, B, D,
                                 kl_beta, inv_count, st);
   return VAE_ERR_ARG;
+}
+
+int vae_nll_elbo_fused(const void* x, const void* recon, int nll_type, const void* kld, const void* add, const void* mi,
+                       float kl_beta, float inv_count, float grad_scale, void* nll, void* loss, void* elbo, float* means,
+                       float* workspace, void* grecon, int64_t B, int64_t D, int dtype, vae_stream_t stream) {
+  if (B < 0 || D <= 0 || D > VAE_MAX_ROW) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  if (!x || !recon || !nll || !loss || !elbo || !means || !workspace || !grecon) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const float cscale = inv_count * grad_scale;
+  if (dtype == VAE_F32)
+    return nll_fused_type<float>(nll_type, x, recon, kld, add, mi, nll, loss, elbo, means, workspace, grecon, cscale,
+                                 B, D, kl_beta, inv_count, st);
+  if (dtype == VAE_BF16)
+    return nll_fused_type<bf16_t>(nll_type, x, recon, kld, add, mi, nll, loss, elbo, means, workspace, grecon, cscale,
+                                  B, D, kl_beta, inv_count, st);
+  return VAE_ERR_ARG;
+}
+
+int vae_nll_fused_grad_finish(void* grecon, const float* gmeans, int64_t n, int dtype, vae_stream_t stream) {
+  if (n < 0 || (dtype != VAE_F32 && dtype != VAE_BF16)) return VAE_ERR_ARG;
+  if (n == 0) return VAE_OK;
+  if (!grecon || !gmeans) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int VN = dtype == VAE_F32 ? 4 : 8;
+  const bool vec = (n % VN == 0) && aligned16(grecon);
+  const int64_t items = vec ? n / VN : n;
+  int64_t blocks = (items + kBlock - 1) / kBlock;
+  const int grid = (int)(blocks < 4096 ? blocks : 4096);
+  if (dtype == VAE_F32) {
+    if (vec) hipLaunchKernelGGL((scale_by_mean_grads_kernel<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)grecon, gmeans, items);
+    else hipLaunchKernelGGL((scale_by_mean_grads_kernel<float, 1>), dim3(grid), dim3(kBlock), 0, st, (float*)grecon, gmeans, items);
+  } else {
+    if (vec) hipLaunchKernelGGL((scale_by_mean_grads_kernel<bf16_t, 8>), dim3(grid), dim3(kBlock), 0, st, (bf16_t*)grecon, gmeans, items);
+    else hipLaunchKernelGGL((scale_by_mean_grads_kernel<bf16_t, 1>), dim3(grid), dim3(kBlock), 0, st, (bf16_t*)grecon, gmeans, items);
+  }
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 
 int vae_elbo_combine_fwd(const void* nll, const void* kld, const void* add, const void* mi, float kl_beta,

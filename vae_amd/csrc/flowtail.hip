@@ -1,0 +1,759 @@
+// Elementwise tails of the flow layers: what is left of a MAF / RealNVP block once the
+// stock GEMMs (masked linears, coupling nets) have run.  All HBM-bound row kernels; the running
+// `logdets += logdet` of FlowSequential (flows/__init__.py:555-557) is folded into each tail through
+// a logdet_in / logdet_out pair, so a block adds no [B]-sized launches of its own.
+//
+// Replaces, from /root/reference/flows/__init__.py:
+//   :121-125, :176-178   MADE / MADESplit 'direct': u = (x - m) * exp(-a); logdet = -sum_f a
+//                        (a = tanh(a) first when pre_exp_tanh)
+//   :524-528, :458-460   CouplingLayer / AdditiveCouplingLayer 'direct':
+//                        log_s = s_raw*(1-mask); t = t_raw*(1-mask); y = x*exp(log_s) + t; logdet = sum log_s
+//   :233-257             BatchNormFlow 'direct': batch mean / var (+eps) over the batch, x_hat, y, logdet
+//   :392-409             Reverse, when it follows a BatchNormFlow: folded into the store (column F-1-j)
+#include "common.hpp"
+#include "../../include/vae_amd.h"
+
+namespace vae {
+
+__device__ __forceinline__ float tanh_acc(float v) { return tanhf(v); }
+
+// per-column fp32 vectors (mask, scale, shift, ...): V consecutive floats (V = 1, 4 or 8), cached loads
+template <int V>
+__device__ __forceinline__ void load_f32(const float* __restrict__ p, float (&out)[V]) {
+  if constexpr (V == 1) {
+    out[0] = p[0];
+  } else {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) {
+      const f4 r = reinterpret_cast<const f4*>(p)[q];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) out[4 * q + i] = r[i];
+    }
+  }
+}
+template <int V, int U>
+__device__ __forceinline__ void load_f32_chunk(const float* __restrict__ base, int j0, int G, int nvec,
+                                               float (&out)[U][V]) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    int j = j0 + u * G;
+    j = j < nvec ? j : nvec - 1;
+    load_f32<V>(base + (int64_t)j * V, out[u]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MADE tail
+// ---------------------------------------------------------------------------------------------
+template <typename T, int V, int U>
+__global__ __launch_bounds__(kBlock) void made_tail_fwd_kernel(
+    const T* __restrict__ x, int64_t sx, const T* __restrict__ m, int64_t sm, const T* __restrict__ a, int64_t sa,
+    T* __restrict__ u, const T* __restrict__ ld_in, T* __restrict__ ld_out, int64_t B, int F, int pre_tanh, int G,
+    int64_t tiles) {
+  const int rpb = kBlock / G;
+  const int sub = threadIdx.x % G;
+  const int rloc = threadIdx.x / G;
+  const int nvec = F / V;
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t row = t * rpb + rloc;
+    float s = 0.f;
+    if (row < B) {
+      for (int j0 = sub; j0 < nvec; j0 += G * U) {
+        float xv[U][V], mv[U][V], av[U][V];
+        load_chunk<T, V, U>(x + row * sx, j0, G, nvec, xv);
+        load_chunk<T, V, U>(m + row * sm, j0, G, nvec, mv);
+        load_chunk<T, V, U>(a + row * sa, j0, G, nvec, av);
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          const int j = j0 + k * G;
+          if (j < nvec) {
+            float o[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+              const float ai = pre_tanh ? tanh_acc(av[k][i]) : av[k][i];
+              o[i] = (xv[k][i] - mv[k][i]) * expf(-ai);
+              s -= ai;
+            }
+            store_vec<T, V>(u + row * F + (int64_t)j * V, o);
+          }
+        }
+      }
+    }
+    s = group_sum(s, G);
+    if (row < B && sub == 0) ld_out[row] = from_f32<T>((ld_in ? to_f32(ld_in[row]) : 0.f) + to_f32(from_f32<T>(s)));
+  }
+}
+
+// gx = gu*exp(-a); gm = -gx; ga = (-u*gu - gld) [* (1 - tanh(a)^2)]
+template <typename T, int V, int U>
+__global__ __launch_bounds__(kBlock) void made_tail_bwd_kernel(
+    const T* __restrict__ u, const T* __restrict__ a, int64_t sa, const T* __restrict__ gu, const T* __restrict__ gld,
+    T* __restrict__ gx, T* __restrict__ gm, int64_t sgm, T* __restrict__ ga, int64_t sga, int64_t B, int F,
+    int pre_tanh, int G, int64_t tiles) {
+  const int rpb = kBlock / G;
+  const int sub = threadIdx.x % G;
+  const int rloc = threadIdx.x / G;
+  const int nvec = F / V;
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t row = t * rpb + rloc;
+    if (row >= B) continue;
+    const float gl = gld ? to_f32(gld[row]) : 0.f;
+    for (int j0 = sub; j0 < nvec; j0 += G * U) {
+      float uv[U][V], av[U][V], gv[U][V];
+      load_chunk<T, V, U>(u + row * F, j0, G, nvec, uv);
+      load_chunk<T, V, U>(a + row * sa, j0, G, nvec, av);
+      if (gu) load_chunk<T, V, U>(gu + row * F, j0, G, nvec, gv);
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int j = j0 + k * G;
+        if (j < nvec) {
+          float ox[V], om[V], oa[V];
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            const float g = gu ? gv[k][i] : 0.f;
+            const float ai = pre_tanh ? tanh_acc(av[k][i]) : av[k][i];
+            ox[i] = g * expf(-ai);
+            om[i] = -ox[i];
+            float d = -uv[k][i] * g - gl;
+            if (pre_tanh) d *= (1.0f - ai * ai);
+            oa[i] = d;
+          }
+          if (gx) store_vec<T, V>(gx + row * F + (int64_t)j * V, ox);
+          store_vec<T, V>(gm + row * sgm + (int64_t)j * V, om);
+          store_vec<T, V>(ga + row * sga + (int64_t)j * V, oa);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// coupling tail (mask: F floats, 1 = pass-through input of the nets, 0 = transformed)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int V, int U>
+__global__ __launch_bounds__(kBlock) void coupling_tail_fwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ s_raw, const T* __restrict__ t_raw, const float* __restrict__ mask,
+    T* __restrict__ y, const T* __restrict__ ld_in, T* __restrict__ ld_out, int64_t B, int F, int G, int64_t tiles) {
+  const int rpb = kBlock / G;
+  const int sub = threadIdx.x % G;
+  const int rloc = threadIdx.x / G;
+  const int nvec = F / V;
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t row = t * rpb + rloc;
+    float s = 0.f;
+    if (row < B) {
+      for (int j0 = sub; j0 < nvec; j0 += G * U) {
+        float xv[U][V], sv[U][V], tv[U][V], mk[U][V];
+        load_chunk<T, V, U>(x + row * F, j0, G, nvec, xv);
+        if (s_raw) load_chunk<T, V, U>(s_raw + row * F, j0, G, nvec, sv);
+        load_chunk<T, V, U>(t_raw + row * F, j0, G, nvec, tv);
+        load_f32_chunk<V, U>(mask, j0, G, nvec, mk);
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          const int j = j0 + k * G;
+          if (j < nvec) {
+            float o[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+              const float inv = 1.0f - mk[k][i];
+              const float ls = s_raw ? sv[k][i] * inv : 0.f;
+              o[i] = xv[k][i] * (s_raw ? expf(ls) : 1.0f) + tv[k][i] * inv;
+              s += ls;
+            }
+            store_vec<T, V>(y + row * F + (int64_t)j * V, o);
+          }
+        }
+      }
+    }
+    s = group_sum(s, G);
+    if (row < B && sub == 0) ld_out[row] = from_f32<T>((ld_in ? to_f32(ld_in[row]) : 0.f) + to_f32(from_f32<T>(s)));
+  }
+}
+
+// gx = gy*exp(log_s) (direct path only); gs_raw = (gy*x*exp(log_s) + gld)*(1-mask); gt_raw = gy*(1-mask)
+template <typename T, int V, int U>
+__global__ __launch_bounds__(kBlock) void coupling_tail_bwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ s_raw, const float* __restrict__ mask, const T* __restrict__ gy,
+    const T* __restrict__ gld, T* __restrict__ gx, T* __restrict__ gs, T* __restrict__ gt, int64_t B, int F, int G,
+    int64_t tiles) {
+  const int rpb = kBlock / G;
+  const int sub = threadIdx.x % G;
+  const int rloc = threadIdx.x / G;
+  const int nvec = F / V;
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t row = t * rpb + rloc;
+    if (row >= B) continue;
+    const float gl = gld ? to_f32(gld[row]) : 0.f;
+    for (int j0 = sub; j0 < nvec; j0 += G * U) {
+      float xv[U][V], sv[U][V], gv[U][V], mk[U][V];
+      if (s_raw) {
+        load_chunk<T, V, U>(x + row * F, j0, G, nvec, xv);
+        load_chunk<T, V, U>(s_raw + row * F, j0, G, nvec, sv);
+      }
+      if (gy) load_chunk<T, V, U>(gy + row * F, j0, G, nvec, gv);
+      load_f32_chunk<V, U>(mask, j0, G, nvec, mk);
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int j = j0 + k * G;
+        if (j < nvec) {
+          float ox[V], os[V], ot[V];
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            const float g = gy ? gv[k][i] : 0.f;
+            const float inv = 1.0f - mk[k][i];
+            const float e = s_raw ? expf(sv[k][i] * inv) : 1.0f;
+            ox[i] = g * e;
+            os[i] = s_raw ? (g * xv[k][i] * e + gl) * inv : 0.f;
+            ot[i] = g * inv;
+          }
+          const int64_t o = row * F + (int64_t)j * V;
+          if (gx) store_vec<T, V>(gx + o, ox);
+          if (gs) store_vec<T, V>(gs + o, os);
+          store_vec<T, V>(gt + o, ot);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNormFlow: column moments over the batch.
+//
+// A lane group owns a row, a lane always the same columns (sub + k*G), so every thread keeps the
+// two running sums of ITS columns in registers while the block walks its row tiles; one LDS step
+// folds the rows of a block, and each block writes one [2][F] partial (plus one float, the
+// block's sum of gld) that a small second kernel adds up in block order, in double.
+//   mode 0 (forward):  f1 = x - c, f2 = (x - c)^2, c = x[0, :]  (shifted: no cancellation)
+//   mode 1 (backward): f1 = gy,    f2 = gy * x_hat;  extra = sum_b gld[b]
+// `rev`: gy / y live in reversed column order (the fused Reverse).
+// ---------------------------------------------------------------------------------------------
+constexpr int kBnChunks = 4;                    // vectors per lane: F <= 4 * G * V
+constexpr int kBnGrid = 256;                    // one block per CU; partials = 256 * 2F floats
+
+template <typename T, int V>
+__device__ __forceinline__ void load_vec_rev(const T* __restrict__ rowp, int j, int nvec, bool rev, float (&out)[V]) {
+  if (!rev) {
+    load_vec<T, V>(rowp + (int64_t)j * V, out);
+  } else {
+    float tmp[V];
+    load_vec<T, V>(rowp + (int64_t)(nvec - 1 - j) * V, tmp);
+#pragma unroll
+    for (int i = 0; i < V; ++i) out[i] = tmp[V - 1 - i];
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(kBlock) void bn_colstats_kernel(
+    const T* __restrict__ x, const T* __restrict__ gy, const T* __restrict__ gld, const float* __restrict__ mean,
+    const float* __restrict__ rstd, float* __restrict__ part, int64_t B, int F, int mode, int rev, int G,
+    int64_t tiles) {
+  __shared__ float lds[kBnChunks * V * kBlock];   // [slot][tid], slot < kBnChunks*V; one statistic at a time
+  const int rpb = kBlock / G;
+  const int sub = threadIdx.x % G;
+  const int rloc = threadIdx.x / G;
+  const int nvec = F / V;
+  float a1[kBnChunks][V], a2[kBnChunks][V], c0[kBnChunks][V], c1[kBnChunks][V];
+  float extra = 0.f;
+#pragma unroll
+  for (int k = 0; k < kBnChunks; ++k) {
+    const int j = sub + k * G;
+#pragma unroll
+    for (int i = 0; i < V; ++i) { a1[k][i] = 0.f; a2[k][i] = 0.f; c0[k][i] = 0.f; c1[k][i] = 1.f; }
+    if (j < nvec) {
+      if (mode == 0) {
+        load_vec<T, V, false>(x + (int64_t)j * V, c0[k]);          // shift: the first row
+      } else {
+        load_f32<V>(mean + (int64_t)j * V, c0[k]);
+        load_f32<V>(rstd + (int64_t)j * V, c1[k]);
+      }
+    }
+  }
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t row = t * rpb + rloc;
+    if (row >= B) continue;
+    if (mode == 1 && gld && sub == 0) extra += to_f32(gld[row]);
+#pragma unroll
+    for (int k = 0; k < kBnChunks; ++k) {
+      const int j = sub + k * G;
+      if (j < nvec) {
+        float xv[V], gv[V];
+        load_vec<T, V>(x + row * F + (int64_t)j * V, xv);
+        if (mode == 1) load_vec_rev<T, V>(gy + row * F, j, nvec, rev != 0, gv);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          if (mode == 0) {
+            const float d = xv[i] - c0[k][i];
+            a1[k][i] += d;
+            a2[k][i] += d * d;
+          } else {
+            a1[k][i] += gv[i];
+            a2[k][i] += gv[i] * ((xv[i] - c0[k][i]) * c1[k][i]);
+          }
+        }
+      }
+    }
+  }
+  // fold the rpb rows of the block (k-major LDS: conflict-free), then one partial per block
+  float* mypart = part + (size_t)blockIdx.x * (2 * (size_t)F + 1);
+  if (rpb > 1) {
+    for (int st = 0; st < 2; ++st) {
+      if (st) __syncthreads();   // the readers of the first statistic are done
+#pragma unroll
+      for (int k = 0; k < kBnChunks; ++k)
+#pragma unroll
+        for (int i = 0; i < V; ++i) lds[(k * V + i) * kBlock + threadIdx.x] = st ? a2[k][i] : a1[k][i];
+      __syncthreads();
+      // thread (rloc, sub) folds the slots q = rloc, rloc + rpb, ... of lane `sub`
+      for (int q = rloc; q < kBnChunks * V; q += rpb) {
+        const int k = q / V, i = q % V;
+        const int j = sub + k * G;
+        if (j < nvec) {
+          float s = 0.f;
+          for (int r = 0; r < rpb; ++r) s += lds[q * kBlock + r * G + sub];
+          mypart[(size_t)st * F + (size_t)j * V + i] = s;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kBnChunks; ++k) {
+      const int j = sub + k * G;
+      if (j < nvec) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          mypart[(size_t)j * V + i] = a1[k][i];
+          mypart[(size_t)F + (size_t)j * V + i] = a2[k][i];
+        }
+      }
+    }
+  }
+  // the block's sum of gld: lanes with sub == 0 hold it
+  __shared__ float ex[kBlock / 64];
+  float e = wave_sum(extra);
+  if ((threadIdx.x & 63) == 0) ex[threadIdx.x >> 6] = e;
+  __syncthreads();
+  if (threadIdx.x == 0) mypart[2 * (size_t)F] = ex[0] + ex[1] + ex[2] + ex[3];
+}
+
+// Second step: 32 columns x 8 partial-groups per block; block order, double.
+//   mode 0: mean = c + S1/B, var = S2/B - (S1/B)^2 + eps; then the per-column constants of the apply:
+//           scale = exp(lg) / sqrt(var), shift = beta, ldc = lg - 0.5 log var, rstd
+//   mode 1: out1 = S1 (sum gy), out2 = S2 (sum gy*x_hat), extra_out[0] = sum gld (block 0)
+__global__ __launch_bounds__(kBlock) void bn_finalize_kernel(
+    const float* __restrict__ part, int nparts, const void* __restrict__ x0, int x_is_bf16, const float* __restrict__ lg,
+    const float* __restrict__ beta, float* __restrict__ o_mean, float* __restrict__ o_var, float* __restrict__ o_scale,
+    float* __restrict__ o_shift, float* __restrict__ o_ldc, float* __restrict__ o_rstd, float* __restrict__ extra_out,
+    int64_t B, int F, float eps, int mode) {
+  __shared__ double l1[8][32], l2[8][32];
+  const int cl = threadIdx.x & 31, pg = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cl;
+  const size_t pstride = 2 * (size_t)F + 1;
+  double s1 = 0.0, s2 = 0.0;
+  if (col < F) {
+    for (int p = pg; p < nparts; p += 8) {
+      s1 += (double)part[p * pstride + col];
+      s2 += (double)part[p * pstride + F + col];
+    }
+  }
+  l1[pg][cl] = s1;
+  l2[pg][cl] = s2;
+  __syncthreads();
+  if (pg == 0 && col < F) {
+    s1 = 0.0; s2 = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) { s1 += l1[g][cl]; s2 += l2[g][cl]; }
+    if (mode == 0) {
+      const float c = x_is_bf16 ? to_f32(((const bf16_t*)x0)[col]) : ((const float*)x0)[col];
+      const double m1 = s1 / (double)B;
+      const float mean = (float)((double)c + m1);
+      const float var = (float)(s2 / (double)B - m1 * m1) + eps;
+      const float r = 1.0f / sqrtf(var);
+      const float sc = expf(lg[col]) * r;
+      o_mean[col] = mean;
+      o_var[col] = var;
+      o_rstd[col] = r;
+      o_scale[col] = sc;
+      o_shift[col] = beta[col];
+      o_ldc[col] = lg[col] - 0.5f * logf(var);
+    } else {
+      o_mean[col] = (float)s1;
+      o_var[col] = (float)s2;
+    }
+  }
+  if (mode == 1 && blockIdx.x == 0 && threadIdx.x == 0) {
+    double e = 0.0;
+    for (int p = 0; p < nparts; ++p) e += (double)part[p * pstride + 2 * (size_t)F];
+    extra_out[0] = (float)e;
+  }
+}
+
+// eval mode / explicit statistics: the per-column constants from given mean / var vectors
+__global__ __launch_bounds__(kBlock) void bn_prepare_kernel(const float* __restrict__ mean, const float* __restrict__ var,
+                                                           const float* __restrict__ lg, const float* __restrict__ beta,
+                                                           float* __restrict__ o_scale, float* __restrict__ o_shift,
+                                                           float* __restrict__ o_ldc, float* __restrict__ o_rstd, int F) {
+  const int col = blockIdx.x * kBlock + threadIdx.x;
+  if (col >= F) return;
+  const float r = 1.0f / sqrtf(var[col]);
+  const float sc = expf(lg[col]) * r;
+  o_rstd[col] = r;
+  o_scale[col] = sc;
+  o_shift[col] = beta[col];
+  o_ldc[col] = lg[col] - 0.5f * logf(var[col]);
+}
+
+// y[b, p(j)] = (x - mean_j)*scale_j + beta_j (the subtraction first, as the reference: x*scale + shift would
+// cancel catastrophically when |mean| >> std);  logdet_out[b] = logdet_in[b] + sum_j ldc_j
+template <typename T, int V, int U>
+__global__ __launch_bounds__(kBlock) void bn_apply_fwd_kernel(
+    const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ ldc, T* __restrict__ y, const T* __restrict__ ld_in, T* __restrict__ ld_out, int64_t B,
+    int F, int rev, int G, int64_t tiles) {
+  const int rpb = kBlock / G;
+  const int sub = threadIdx.x % G;
+  const int rloc = threadIdx.x / G;
+  const int nvec = F / V;
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t row = t * rpb + rloc;
+    float s = 0.f;
+    if (row < B) {
+      for (int j0 = sub; j0 < nvec; j0 += G * U) {
+        float xv[U][V], mu[U][V], sc[U][V], sh[U][V], lc[U][V];
+        load_chunk<T, V, U>(x + row * F, j0, G, nvec, xv);
+        load_f32_chunk<V, U>(mean, j0, G, nvec, mu);
+        load_f32_chunk<V, U>(scale, j0, G, nvec, sc);
+        load_f32_chunk<V, U>(shift, j0, G, nvec, sh);
+        load_f32_chunk<V, U>(ldc, j0, G, nvec, lc);
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          const int j = j0 + k * G;
+          if (j < nvec) {
+            float o[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+              const float v = (xv[k][i] - mu[k][i]) * sc[k][i] + sh[k][i];
+              if (rev) o[V - 1 - i] = v; else o[i] = v;
+              s += lc[k][i];
+            }
+            store_vec<T, V>(y + row * F + (int64_t)(rev ? nvec - 1 - j : j) * V, o);
+          }
+        }
+      }
+    }
+    s = group_sum(s, G);
+    if (row < B && sub == 0) ld_out[row] = from_f32<T>((ld_in ? to_f32(ld_in[row]) : 0.f) + to_f32(from_f32<T>(s)));
+  }
+}
+
+// training: gx = scale*(gy - S1/B - x_hat*S2/B) - GLD*x_hat*rstd/B ;  eval: gx = scale*gy
+template <typename T, int V, int U>
+__global__ __launch_bounds__(kBlock) void bn_apply_bwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ gy, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ scale, const float* __restrict__ s1, const float* __restrict__ s2,
+    const float* __restrict__ gld_sum, T* __restrict__ gx, int64_t B, int F, float inv_b, int training, int rev, int G,
+    int64_t tiles) {
+  const int rpb = kBlock / G;
+  const int sub = threadIdx.x % G;
+  const int rloc = threadIdx.x / G;
+  const int nvec = F / V;
+  const float gls = training ? gld_sum[0] * inv_b : 0.f;
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t row = t * rpb + rloc;
+    if (row >= B) continue;
+    for (int j0 = sub; j0 < nvec; j0 += G * U) {
+      float xv[U][V], gv[U][V], mu[U][V], rs[U][V], sc[U][V], c1[U][V], c2[U][V];
+      if (training) {
+        load_chunk<T, V, U>(x + row * F, j0, G, nvec, xv);
+        load_f32_chunk<V, U>(mean, j0, G, nvec, mu);
+        load_f32_chunk<V, U>(rstd, j0, G, nvec, rs);
+        load_f32_chunk<V, U>(s1, j0, G, nvec, c1);
+        load_f32_chunk<V, U>(s2, j0, G, nvec, c2);
+      }
+      load_f32_chunk<V, U>(scale, j0, G, nvec, sc);
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        int jj = j0 + k * G;
+        jj = jj < nvec ? jj : nvec - 1;
+        load_vec_rev<T, V>(gy + row * F, jj, nvec, rev != 0, gv[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int j = j0 + k * G;
+        if (j < nvec) {
+          float o[V];
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            if (training) {
+              const float xh = (xv[k][i] - mu[k][i]) * rs[k][i];
+              o[i] = sc[k][i] * (gv[k][i] - c1[k][i] * inv_b - xh * c2[k][i] * inv_b) - gls * xh * rs[k][i];
+            } else {
+              o[i] = sc[k][i] * gv[k][i];
+            }
+          }
+          store_vec<T, V>(gx + row * F + (int64_t)j * V, o);
+        }
+      }
+    }
+  }
+}
+
+// geometry for the column-moment kernel: the row must fit kBnChunks vectors per lane
+static bool bn_geom(int64_t B, int64_t nvec, int* G_out, int64_t* tiles, int* grid) {
+  int G = 1;
+  while (G < kBlock && (int64_t)G * kBnChunks < nvec) G <<= 1;
+  if ((int64_t)G * kBnChunks < nvec) return false;
+  if (G < 16 && nvec >= 16) G = 16;   // keep the partial stores reasonably coalesced
+  while (G > nvec && G > 1) G >>= 1;
+  if ((int64_t)G * kBnChunks < nvec) G <<= 1;
+  const int rpb = kBlock / G;
+  *G_out = G;
+  *tiles = (B + rpb - 1) / rpb;
+  *grid = (int)(*tiles < kBnGrid ? *tiles : kBnGrid);
+  return true;
+}
+
+template <typename T>
+static int made_fwd_dispatch(const void* x, int64_t sx, const void* m, int64_t sm, const void* a, int64_t sa, void* u,
+                             const void* ld_in, void* ld_out, int64_t B, int64_t F, int pre_tanh, hipStream_t st) {
+  constexpr int VN = VecOf<T>::n;
+  const bool vec = (F % VN == 0) && (sx % VN == 0) && (sm % VN == 0) && (sa % VN == 0) && aligned16(x) &&
+                   aligned16(m) && aligned16(a) && aligned16(u);
+  const RowGeom g = row_geom(B, vec ? F / VN : F, kGridStream);
+  if (vec) {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((made_tail_fwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, st,
+                                         (const T*)x, sx, (const T*)m, sm, (const T*)a, sa, (T*)u, (const T*)ld_in,
+                                         (T*)ld_out, B, (int)F, pre_tanh, g.G, g.tiles));
+  } else {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((made_tail_fwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, st,
+                                         (const T*)x, sx, (const T*)m, sm, (const T*)a, sa, (T*)u, (const T*)ld_in,
+                                         (T*)ld_out, B, (int)F, pre_tanh, g.G, g.tiles));
+  }
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+template <typename T>
+static int made_bwd_dispatch(const void* u, const void* a, int64_t sa, const void* gu, const void* gld, void* gx,
+                             void* gm, int64_t sgm, void* ga, int64_t sga, int64_t B, int64_t F, int pre_tanh,
+                             hipStream_t st) {
+  constexpr int VN = VecOf<T>::n;
+  const bool vec = (F % VN == 0) && (sa % VN == 0) && (sgm % VN == 0) && (sga % VN == 0) && aligned16(u) &&
+                   aligned16(a) && (!gu || aligned16(gu)) && (!gx || aligned16(gx)) && aligned16(gm) && aligned16(ga);
+  const RowGeom g = row_geom(B, vec ? F / VN : F, kGridStream);
+  if (vec) {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((made_tail_bwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, st,
+                                         (const T*)u, (const T*)a, sa, (const T*)gu, (const T*)gld, (T*)gx, (T*)gm, sgm,
+                                         (T*)ga, sga, B, (int)F, pre_tanh, g.G, g.tiles));
+  } else {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((made_tail_bwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, st,
+                                         (const T*)u, (const T*)a, sa, (const T*)gu, (const T*)gld, (T*)gx, (T*)gm, sgm,
+                                         (T*)ga, sga, B, (int)F, pre_tanh, g.G, g.tiles));
+  }
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+template <typename T>
+static int coupling_fwd_dispatch(const void* x, const void* s_raw, const void* t_raw, const float* mask, void* y,
+                                 const void* ld_in, void* ld_out, int64_t B, int64_t F, hipStream_t st) {
+  constexpr int VN = VecOf<T>::n;
+  const bool vec = (F % VN == 0) && aligned16(x) && (!s_raw || aligned16(s_raw)) && aligned16(t_raw) &&
+                   aligned16(mask) && aligned16(y);
+  const RowGeom g = row_geom(B, vec ? F / VN : F, kGridStream);
+  if (vec) {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((coupling_tail_fwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, st,
+                                         (const T*)x, (const T*)s_raw, (const T*)t_raw, mask, (T*)y, (const T*)ld_in,
+                                         (T*)ld_out, B, (int)F, g.G, g.tiles));
+  } else {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((coupling_tail_fwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, st,
+                                         (const T*)x, (const T*)s_raw, (const T*)t_raw, mask, (T*)y, (const T*)ld_in,
+                                         (T*)ld_out, B, (int)F, g.G, g.tiles));
+  }
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+template <typename T>
+static int coupling_bwd_dispatch(const void* x, const void* s_raw, const float* mask, const void* gy, const void* gld,
+                                 void* gx, void* gs, void* gt, int64_t B, int64_t F, hipStream_t st) {
+  constexpr int VN = VecOf<T>::n;
+  const bool vec = (F % VN == 0) && aligned16(x) && (!s_raw || aligned16(s_raw)) && aligned16(mask) &&
+                   (!gy || aligned16(gy)) && (!gx || aligned16(gx)) && (!gs || aligned16(gs)) && aligned16(gt);
+  const RowGeom g = row_geom(B, vec ? F / VN : F, kGridStream);
+  if (vec) {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((coupling_tail_bwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, st,
+                                         (const T*)x, (const T*)s_raw, mask, (const T*)gy, (const T*)gld, (T*)gx,
+                                         (T*)gs, (T*)gt, B, (int)F, g.G, g.tiles));
+  } else {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((coupling_tail_bwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, st,
+                                         (const T*)x, (const T*)s_raw, mask, (const T*)gy, (const T*)gld, (T*)gx,
+                                         (T*)gs, (T*)gt, B, (int)F, g.G, g.tiles));
+  }
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+// stats layout (floats, caller-owned, >= vae_bnflow_stats_floats(F)):
+//   [0,F) mean | [F,2F) var | [2F,3F) rstd | [3F,4F) scale | [4F,5F) shift | [5F,6F) ldc |
+//   [6F,7F) S1 | [7F,8F) S2 | [8F] sum gld | pad to 8F+4 | block partials kBnGrid * (2F+1)
+static size_t bn_stats_floats(int64_t F) { return 8 * (size_t)F + 4 + (size_t)kBnGrid * (2 * (size_t)F + 1); }
+
+template <typename T>
+static int bn_fwd_dispatch(const void* x, const float* lg, const float* beta, const float* mean_in, const float* var_in,
+                           float* stats, void* y, const void* ld_in, void* ld_out, int64_t B, int64_t F, float eps,
+                           int training, int rev, hipStream_t st) {
+  constexpr int VN = VecOf<T>::n;
+  const bool vec = (F % VN == 0) && aligned16(x) && aligned16(y) && aligned16(stats);
+  float *mean = stats, *var = stats + F, *rstd = stats + 2 * F, *scale = stats + 3 * F, *shift = stats + 4 * F,
+        *ldc = stats + 5 * F, *part = stats + 8 * F + 4;
+  if (training) {
+    int G, grid;
+    int64_t tiles;
+    if (!bn_geom(B, vec ? F / VN : F, &G, &tiles, &grid)) return VAE_ERR_ARG;
+    if (vec)
+      hipLaunchKernelGGL((bn_colstats_kernel<T, VN>), dim3(grid), dim3(kBlock), 0, st, (const T*)x, (const T*)nullptr,
+                         (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, part, B, (int)F, 0, 0, G, tiles);
+    else
+      hipLaunchKernelGGL((bn_colstats_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, st, (const T*)x, (const T*)nullptr,
+                         (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, part, B, (int)F, 0, 0, G, tiles);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((F + 31) / 32)), dim3(kBlock), 0, st, part, grid, x,
+                       (int)(sizeof(T) == 2), lg, beta, mean, var, scale, shift, ldc, rstd, (float*)nullptr, B, (int)F,
+                       eps, 0);
+  } else {
+    if (hipMemcpyAsync(mean, mean_in, F * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(var, var_in, F * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return VAE_ERR_LAUNCH;
+    hipLaunchKernelGGL(bn_prepare_kernel, dim3((unsigned)((F + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, mean_in,
+                       var_in, lg, beta, scale, shift, ldc, rstd, (int)F);
+  }
+  const RowGeom g = row_geom(B, vec ? F / VN : F, kGridStream);
+  if (vec) {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((bn_apply_fwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, st,
+                                         (const T*)x, mean, scale, shift, ldc, (T*)y, (const T*)ld_in, (T*)ld_out, B, (int)F,
+                                         rev, g.G, g.tiles));
+  } else {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((bn_apply_fwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, st,
+                                         (const T*)x, mean, scale, shift, ldc, (T*)y, (const T*)ld_in, (T*)ld_out, B, (int)F,
+                                         rev, g.G, g.tiles));
+  }
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+template <typename T>
+static int bn_bwd_dispatch(const void* x, const void* gy, const void* gld, float* stats, void* gx, int64_t B, int64_t F,
+                           int training, int rev, hipStream_t st) {
+  constexpr int VN = VecOf<T>::n;
+  const bool vec = (F % VN == 0) && aligned16(x) && aligned16(gy) && aligned16(gx) && aligned16(stats);
+  float *mean = stats, *rstd = stats + 2 * F, *scale = stats + 3 * F, *s1 = stats + 6 * F, *s2 = stats + 7 * F,
+        *gsum = stats + 8 * F, *part = stats + 8 * F + 4;
+  int G, grid;
+  int64_t tiles;
+  if (!bn_geom(B, vec ? F / VN : F, &G, &tiles, &grid)) return VAE_ERR_ARG;
+  if (vec)
+    hipLaunchKernelGGL((bn_colstats_kernel<T, VN>), dim3(grid), dim3(kBlock), 0, st, (const T*)x, (const T*)gy,
+                       (const T*)gld, mean, rstd, part, B, (int)F, 1, rev, G, tiles);
+  else
+    hipLaunchKernelGGL((bn_colstats_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, st, (const T*)x, (const T*)gy,
+                       (const T*)gld, mean, rstd, part, B, (int)F, 1, rev, G, tiles);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((F + 31) / 32)), dim3(kBlock), 0, st, part, grid,
+                     (const void*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, s1, s2, (float*)nullptr,
+                     (float*)nullptr, (float*)nullptr, (float*)nullptr, gsum, B, (int)F, 0.f, 1);
+  const RowGeom g = row_geom(B, vec ? F / VN : F, kGridStream);
+  const float inv_b = 1.0f / (float)B;
+  if (vec) {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, st,
+                                         (const T*)x, (const T*)gy, mean, rstd, scale, s1, s2, gsum, (T*)gx, B, (int)F,
+                                         inv_b, training, rev, g.G, g.tiles));
+  } else {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, st,
+                                         (const T*)x, (const T*)gy, mean, rstd, scale, s1, s2, gsum, (T*)gx, B, (int)F,
+                                         inv_b, training, rev, g.G, g.tiles));
+  }
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+}  // namespace vae
+
+using namespace vae;
+
+extern "C" {
+
+int vae_made_tail_fwd(const void* x, int64_t stride_x, const void* m, int64_t stride_m, const void* a, int64_t stride_a,
+                      void* u, const void* logdet_in, void* logdet_out, int64_t B, int64_t F, int pre_exp_tanh,
+                      int dtype, vae_stream_t stream) {
+  if (B < 0 || F <= 0 || F > VAE_MAX_ROW) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  if (!x || !m || !a || !u || !logdet_out) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VAE_F32)
+    return made_fwd_dispatch<float>(x, stride_x, m, stride_m, a, stride_a, u, logdet_in, logdet_out, B, F, pre_exp_tanh, st);
+  if (dtype == VAE_BF16)
+    return made_fwd_dispatch<bf16_t>(x, stride_x, m, stride_m, a, stride_a, u, logdet_in, logdet_out, B, F, pre_exp_tanh, st);
+  return VAE_ERR_ARG;
+}
+
+int vae_made_tail_bwd(const void* u, const void* a, int64_t stride_a, const void* gu, const void* glogdet, void* gx,
+                      void* gm, int64_t stride_gm, void* ga, int64_t stride_ga, int64_t B, int64_t F, int pre_exp_tanh,
+                      int dtype, vae_stream_t stream) {
+  if (B < 0 || F <= 0 || F > VAE_MAX_ROW) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  if (!u || !a || !gm || !ga) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VAE_F32)
+    return made_bwd_dispatch<float>(u, a, stride_a, gu, glogdet, gx, gm, stride_gm, ga, stride_ga, B, F, pre_exp_tanh, st);
+  if (dtype == VAE_BF16)
+    return made_bwd_dispatch<bf16_t>(u, a, stride_a, gu, glogdet, gx, gm, stride_gm, ga, stride_ga, B, F, pre_exp_tanh, st);
+  return VAE_ERR_ARG;
+}
+
+int vae_coupling_tail_fwd(const void* x, const void* s_raw, const void* t_raw, const float* mask, void* y,
+                          const void* logdet_in, void* logdet_out, int64_t B, int64_t F, int dtype,
+                          vae_stream_t stream) {
+  if (B < 0 || F <= 0 || F > VAE_MAX_ROW) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  if (!x || !t_raw || !mask || !y || !logdet_out) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VAE_F32) return coupling_fwd_dispatch<float>(x, s_raw, t_raw, mask, y, logdet_in, logdet_out, B, F, st);
+  if (dtype == VAE_BF16) return coupling_fwd_dispatch<bf16_t>(x, s_raw, t_raw, mask, y, logdet_in, logdet_out, B, F, st);
+  return VAE_ERR_ARG;
+}
+
+int vae_coupling_tail_bwd(const void* x, const void* s_raw, const float* mask, const void* gy, const void* glogdet,
+                          void* gx, void* gs_raw, void* gt_raw, int64_t B, int64_t F, int dtype, vae_stream_t stream) {
+  if (B < 0 || F <= 0 || F > VAE_MAX_ROW) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  if (!x || !mask || !gt_raw || (s_raw && !gs_raw)) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VAE_F32) return coupling_bwd_dispatch<float>(x, s_raw, mask, gy, glogdet, gx, gs_raw, gt_raw, B, F, st);
+  if (dtype == VAE_BF16) return coupling_bwd_dispatch<bf16_t>(x, s_raw, mask, gy, glogdet, gx, gs_raw, gt_raw, B, F, st);
+  return VAE_ERR_ARG;
+}
+
+size_t vae_bnflow_stats_floats(int64_t F) { return F > 0 ? bn_stats_floats(F) : 0; }
+
+int vae_bnflow_fwd(const void* x, const float* log_gamma, const float* beta, const float* mean_in, const float* var_in,
+                   float* stats, void* y, const void* logdet_in, void* logdet_out, int64_t B, int64_t F, float eps,
+                   int training, int reverse, int dtype, vae_stream_t stream) {
+  if (B < 0 || F <= 0 || F > VAE_MAX_BN_ROW) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  if (!x || !log_gamma || !beta || !stats || !y || !logdet_out) return VAE_ERR_ARG;
+  if (!training && (!mean_in || !var_in)) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VAE_F32)
+    return bn_fwd_dispatch<float>(x, log_gamma, beta, mean_in, var_in, stats, y, logdet_in, logdet_out, B, F, eps,
+                                  training, reverse, st);
+  if (dtype == VAE_BF16)
+    return bn_fwd_dispatch<bf16_t>(x, log_gamma, beta, mean_in, var_in, stats, y, logdet_in, logdet_out, B, F, eps,
+                                   training, reverse, st);
+  return VAE_ERR_ARG;
+}
+
+int vae_bnflow_bwd(const void* x, const void* gy, const void* glogdet, float* stats, void* gx, int64_t B, int64_t F,
+                   int training, int reverse, int dtype, vae_stream_t stream) {
+  if (B < 0 || F <= 0 || F > VAE_MAX_BN_ROW) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  if (!x || !gy || !stats || !gx) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VAE_F32) return bn_bwd_dispatch<float>(x, gy, glogdet, stats, gx, B, F, training, reverse, st);
+  if (dtype == VAE_BF16) return bn_bwd_dispatch<bf16_t>(x, gy, glogdet, stats, gx, B, F, training, reverse, st);
+  return VAE_ERR_ARG;
+}
+
+}  // extern "C"

@@ -893,3 +893,150 @@ def nll_multi_elbo(x, recons, nll_type, kld=None, add=None, mi=None, kl_beta=1.0
         return total, None, None, None
     loss, elbo, means = elbo_combine(total, kld=kld, add=add, mi=mi, kl_beta=kl_beta, inv_count=inv_count)
     return total, loss, elbo, means
+
+
+# --------------------------------------------------------------------------------------
+# Flow-layer tails (flows/__init__.py): MADE / MADESplit, coupling, BatchNormFlow (+ Reverse).
+# The running logdet of FlowSequential rides along as a [B] tensor (logdet_in -> logdet_out).
+# --------------------------------------------------------------------------------------
+class _MadeTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, m, a, logdet_in, pre_tanh):
+        """a None: `m` is the packed [B, 2F] trunk output [m | a] (MADE); else two [B, F] tensors (MADESplit)."""
+        ctx.set_materialize_grads(False)
+        dev = check_device(x, m, a, logdet_in)
+        B, F = x.shape
+        packed = a is None
+        u = torch.empty((B, F), dtype=x.dtype, device=dev)
+        ld = torch.empty((B,), dtype=x.dtype, device=dev)
+        import ctypes
+        a_ptr = ctypes.c_void_p(m.data_ptr() + F * m.element_size()) if packed else ptr(a)
+        with _Guard(dev):
+            call('vae_made_tail_fwd', ptr(x), x.stride(0), ptr(m), m.stride(0), a_ptr, m.stride(0) if packed else
+                 a.stride(0), ptr(u), ptr(logdet_in), ptr(ld), B, F, int(pre_tanh), dtype_code(x), stream_ptr(dev))
+        ctx.save_for_backward(u, m, a)
+        ctx.cfg = (packed, pre_tanh, logdet_in is not None)
+        return u, ld
+
+    @staticmethod
+    def backward(ctx, gu, gld):
+        u, m, a = ctx.saved_tensors
+        packed, pre_tanh, has_ld = ctx.cfg
+        dev = u.device
+        B, F = u.shape
+        import ctypes
+        gu, gld = _dense(gu), _dense(gld)
+        gx = torch.empty_like(u) if ctx.needs_input_grad[0] else None
+        if packed:
+            gma = torch.empty((B, 2 * F), dtype=u.dtype, device=dev)
+            gm_p, ga_p, sg = ptr(gma), ctypes.c_void_p(gma.data_ptr() + F * gma.element_size()), 2 * F
+            a_p, sa = ctypes.c_void_p(m.data_ptr() + F * m.element_size()), m.stride(0)
+        else:
+            gm, ga = torch.empty_like(u), torch.empty_like(u)
+            gm_p, ga_p, sg = ptr(gm), ptr(ga), F
+            a_p, sa = ptr(a), a.stride(0)
+        with _Guard(dev):
+            call('vae_made_tail_bwd', ptr(u), a_p, sa, ptr(gu), ptr(gld), ptr(gx), gm_p, sg, ga_p, sg, B, F,
+                 int(pre_tanh), dtype_code(u), stream_ptr(dev))
+        gin = gld if has_ld else None
+        if packed:
+            return gx, gma, None, gin, None
+        return gx, gm, ga, gin, None
+
+
+def made_tail(x, m, a=None, logdet_in=None, pre_exp_tanh=False):
+    """u = (x - m) * exp(-a), logdet_out = logdet_in - sum_f a  (flows/__init__.py:121-125, :176-178).
+    `a` None: `m` is MADE's packed trunk output [B, 2F] = [m | a].  Returns (u [B, F], logdet_out [B])."""
+    x = _rows(x)
+    m = _rows(m)
+    a = None if a is None else _rows(a)
+    ld = None if logdet_in is None else logdet_in.reshape(-1).contiguous()
+    return _MadeTail.apply(x, m, a, ld, bool(pre_exp_tanh))
+
+
+class _CouplingTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s_raw, t_raw, mask, logdet_in):
+        ctx.set_materialize_grads(False)
+        dev = check_device(x, s_raw, t_raw, mask, logdet_in)
+        B, F = x.shape
+        y = torch.empty_like(x)
+        ld = torch.empty((B,), dtype=x.dtype, device=dev)
+        with _Guard(dev):
+            call('vae_coupling_tail_fwd', ptr(x), ptr(s_raw), ptr(t_raw), ptr(mask), ptr(y), ptr(logdet_in), ptr(ld),
+                 B, F, dtype_code(x), stream_ptr(dev))
+        ctx.save_for_backward(x, s_raw, mask)
+        ctx.has_ld = logdet_in is not None
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, gy, gld):
+        x, s_raw, mask = ctx.saved_tensors
+        dev = x.device
+        B, F = x.shape
+        gy, gld = _dense(gy), _dense(gld)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gs = torch.empty_like(x) if s_raw is not None else None
+        gt = torch.empty_like(x)
+        with _Guard(dev):
+            call('vae_coupling_tail_bwd', ptr(x), ptr(s_raw), ptr(mask), ptr(gy), ptr(gld), ptr(gx), ptr(gs), ptr(gt),
+                 B, F, dtype_code(x), stream_ptr(dev))
+        return gx, gs, gt, None, (gld if ctx.has_ld else None)
+
+
+def coupling_tail(x, s_raw, t_raw, mask, logdet_in=None):
+    """y = x * exp(s_raw*(1-mask)) + t_raw*(1-mask), logdet_out = logdet_in + sum_f s_raw*(1-mask)
+    (flows/__init__.py:524-528); s_raw None = the additive layer (:458-460).  mask: [F] floats."""
+    x = x.contiguous()
+    mask = mask.to(device=x.device, dtype=torch.float32).contiguous()
+    ld = None if logdet_in is None else logdet_in.reshape(-1).contiguous()
+    return _CouplingTail.apply(x, _dense(s_raw), t_raw.contiguous(), mask, ld)
+
+
+class _BNFlow(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, log_gamma, beta, mean_in, var_in, logdet_in, eps, training, reverse):
+        ctx.set_materialize_grads(False)
+        dev = check_device(x, log_gamma, beta, mean_in, var_in, logdet_in)
+        B, F = x.shape
+        y = torch.empty_like(x)
+        ld = torch.empty((B,), dtype=x.dtype, device=dev)
+        stats = torch.empty((_lib.load().vae_bnflow_stats_floats(F),), dtype=torch.float32, device=dev)
+        lg32, b32 = log_gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        with _Guard(dev):
+            call('vae_bnflow_fwd', ptr(x), ptr(lg32), ptr(b32), ptr(mean_in), ptr(var_in), ptr(stats), ptr(y),
+                 ptr(logdet_in), ptr(ld), B, F, eps, int(training), int(reverse), dtype_code(x), stream_ptr(dev))
+        ctx.save_for_backward(x, lg32, stats)
+        ctx.cfg = (training, reverse, logdet_in is not None, log_gamma.dtype)
+        ctx.mark_non_differentiable(stats)
+        return y, ld, stats
+
+    @staticmethod
+    def backward(ctx, gy, gld, _gstats):
+        x, lg32, stats = ctx.saved_tensors
+        training, reverse, has_ld, pdt = ctx.cfg
+        dev = x.device
+        B, F = x.shape
+        gld = _dense(gld)
+        gy = torch.zeros_like(x) if gy is None else gy.contiguous()
+        gx = torch.empty_like(x)
+        with _Guard(dev):
+            call('vae_bnflow_bwd', ptr(x), ptr(gy), ptr(gld), ptr(stats), ptr(gx), B, F, int(training), int(reverse),
+                 dtype_code(x), stream_ptr(dev))
+        g_beta = stats[6 * F:7 * F].to(pdt)
+        g_lg = (torch.exp(lg32) * stats[7 * F:8 * F] + stats[8 * F]).to(pdt)
+        return gx, g_lg, g_beta, None, None, (gld if has_ld else None), None, None, None
+
+
+def bnflow(x, log_gamma, beta, running_mean=None, running_var=None, logdet_in=None, eps=1e-5, training=True,
+           reverse=False):
+    """BatchNormFlow 'direct' (flows/__init__.py:233-257), optionally with the Reverse that follows it in a
+    MAF block folded into the store.  Returns (y [B, F], logdet_out [B], batch_mean [F], batch_var [F]) --
+    the last two are what the caller folds into its running statistics (:240-246)."""
+    x = x.contiguous()
+    ld = None if logdet_in is None else logdet_in.reshape(-1).contiguous()
+    F = x.shape[1]
+    mi = None if training else running_mean.float().contiguous()
+    vi = None if training else running_var.float().contiguous()
+    y, ldo, stats = _BNFlow.apply(x, log_gamma, beta, mi, vi, ld, float(eps), bool(training), bool(reverse))
+    return y, ldo, stats[:F], stats[F:2 * F]
