@@ -8,8 +8,12 @@ Workload (BASELINE.json configs[1]): simple_vae, IsotropicGaussian latent 512, B
 per GPU, 1x28x28 Bernoulli NLL, fp32, synthetic inputs resident in HBM.  One step = one pass of
 the hot path over one batch, forward and backward:
 
-    gauss_reparam_kl_fwd -> nll_elbo_fwd -> [N>1: one packed all-reduce of the 8 batch scalars]
-    -> nll_elbo_bwd -> gauss_reparam_kl_bwd
+    gauss_reparam_kl_fwd -> nll_elbo_fused (forward AND d loss_mean / d recon in one read of x, recon)
+    -> [N>1: one packed all-reduce of the 8 batch scalars] -> nll_fused_grad_finish (device-side rescale,
+    a no-op for loss_mean.backward()'s unit gradient) + elbo_combine_bwd ([B]: d kld) -> gauss_reparam_kl_bwd
+
+(`--two-pass` times the reference-shaped sequence instead: nll_elbo_fwd ... nll_elbo_bwd, which reads x and
+recon twice; both produce the same outputs and gradients.)
 
 The encoder/decoder networks are not part of the path (stock PyTorch in the reference's host
 project); their outputs (encoder logits, decoder logits) and the decoder's gradient w.r.t. z are
@@ -42,6 +46,8 @@ def algorithmic_bytes(B):
         'gauss_reparam_kl_bwd': (24 * L + 4) * B,   # logits 8L + noise 4L + gz 4L + gkl 4 + glogits 8L
         'nll_elbo_fwd': (8 * D + 12) * B,           # x 4D + recon 4D + kld 4 + loss, elbo 8
         'nll_elbo_bwd': (12 * D) * B,               # x 4D + recon 4D + grecon 4D
+        'nll_elbo_fused': (12 * D + 12) * B,        # x 4D + recon 4D + grecon 4D + kld 4 + loss, elbo 8
+        'grad_finish': 12 * B,                      # gmeans -> d kld [B] (+ the skipped rescale): latency only
     }
 
 
@@ -75,6 +81,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=B_PER_GPU, help='samples per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--two-pass', action='store_true', help='separate NLL forward and backward kernels')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -140,7 +147,9 @@ def main():
     mean_scale = 1.0 / (B * world * L)
     row0 = rank * B
 
-    names = ['gauss_reparam_kl_fwd', 'nll_elbo_fwd', 'nll_elbo_bwd', 'gauss_reparam_kl_bwd']
+    fused = not args.two_pass
+    names = ['gauss_reparam_kl_fwd', 'nll_elbo_fused', 'grad_finish', 'gauss_reparam_kl_bwd'] if fused else \
+        ['gauss_reparam_kl_fwd', 'nll_elbo_fwd', 'nll_elbo_bwd', 'gauss_reparam_kl_bwd']
     pmeans = ctypes_off(scalars, 6)
 
     def step(ev=None):
@@ -151,14 +160,22 @@ def main():
         call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, ptr(noise), ptr(z), L, ptr(logvar), ptr(kl), pmeans,
              ptr(ws), B, L, 1e-6, mean_scale, 1, 0, 0, row0, 0, st)
         mark(1)
-        call('vae_nll_elbo_fwd', ptr(x), ptr(recon), 0, ptr(kl), None, None, 1.0, inv_count, ptr(nll), ptr(loss),
-             ptr(elbo), ptr(scalars), ptr(ws), B, D, 0, st)
+        if fused:
+            call('vae_nll_elbo_fused', ptr(x), ptr(recon), 0, ptr(kl), None, None, 1.0, inv_count, 1.0, ptr(nll),
+                 ptr(loss), ptr(elbo), ptr(scalars), ptr(ws), ptr(grecon), B, D, 0, st)
+        else:
+            call('vae_nll_elbo_fwd', ptr(x), ptr(recon), 0, ptr(kl), None, None, 1.0, inv_count, ptr(nll), ptr(loss),
+                 ptr(elbo), ptr(scalars), ptr(ws), B, D, 0, st)
         mark(2)
         if dist is not None:
             all_reduce(scalars)               # global-batch means (abstract_vae.py:381-387) in one message
         mark(3)
-        call('vae_nll_elbo_bwd', ptr(x), ptr(recon), 0, None, None, None, ptr(gmeans), 1.0, inv_count, ptr(grecon),
-             ptr(gkld), None, None, B, D, 0, st)
+        if fused:
+            call('vae_nll_fused_grad_finish', ptr(grecon), ptr(gmeans), B * D, 0, st)
+            call('vae_elbo_combine_bwd', None, None, ptr(gmeans), 1.0, inv_count, None, ptr(gkld), None, None, B, 0, st)
+        else:
+            call('vae_nll_elbo_bwd', ptr(x), ptr(recon), 0, None, None, None, ptr(gmeans), 1.0, inv_count,
+                 ptr(grecon), ptr(gkld), None, None, B, D, 0, st)
         mark(4)
         call('vae_gauss_reparam_kl_bwd', ptr(logits), 2 * L, ptr(noise), ptr(gz), L, None, ptr(gkld), None,
              ptr(glogits), 2 * L, B, L, 1e-6, mean_scale, 1, 0, 0, row0, 0, st)
@@ -186,8 +203,7 @@ def main():
         dt = float(t.item())
 
     # per-kernel average durations from the HIP events recorded on the launch stream during the timed steps
-    seg = {'gauss_reparam_kl_fwd': (0, 1), 'nll_elbo_fwd': (1, 2), 'nll_elbo_bwd': (3, 4),
-           'gauss_reparam_kl_bwd': (4, 5)}
+    seg = {'gauss_reparam_kl_fwd': (0, 1), names[1]: (1, 2), names[2]: (3, 4), 'gauss_reparam_kl_bwd': (4, 5)}
     dur_ms = {n: sum(e[a].elapsed_time(e[b]) for e in events) / args.steps for n, (a, b) in seg.items()}
     sanity = float(scalars[0].item())
     if not (sanity == sanity):
@@ -235,18 +251,30 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
+            # profiles/traffic.json: PMC bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, scripts/summarize_pmc.py),
+            # keyed by bench kernel name or by the full kernel symbol with a short 'kernel' field
+            short = {'gauss_reparam_kl_fwd': 'gauss_fwd_kernel', 'gauss_reparam_kl_bwd': 'gauss_bwd_kernel',
+                     'nll_elbo_fwd': 'nll_elbo_fwd_kernel', 'nll_elbo_bwd': 'nll_elbo_bwd_kernel',
+                     'nll_elbo_fused': 'nll_elbo_fused_kernel'}.get(dom)
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                tj = json.load(open(tpath))
+                if isinstance(tj.get(dom), (int, float)):
+                    traffic = tj[dom]
+                else:
+                    for v in tj.values():
+                        if isinstance(v, dict) and v.get('kernel') == short:
+                            traffic = int(v['hbm_bytes_per_launch'])
             except Exception:
                 traffic = None
-        total_bytes = sum(ab.values())
+        total_bytes = sum(ab[n] for n in names)
         ksum = sum(dur_ms.values())
         out = {
             'metric': 'ELBO-step samples/sec', 'value': B * world * args.steps / dt, 'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'configs[1]: simple_vae IsotropicGaussian latent 512, B=%d per GPU, 1x28x28 '
-                                   'Bernoulli NLL; step = reparam+KL fwd, NLL+ELBO fwd, both backward' % B,
+                                   'Bernoulli NLL; step = reparam+KL fwd, NLL+ELBO fwd, both backward (%s)'
+                                   % (B, 'NLL forward and gradient in one pass' if fused else 'two-pass NLL'),
                        'global_batch': B * world, 'latent': L, 'pixels': D, 'parallelism': 'dp%d' % world,
                        'noise': 'injected (resident in HBM)'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': kernels[dom]['achieved_GBs'],

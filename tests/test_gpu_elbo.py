@@ -172,3 +172,87 @@ def test_bf16_nll():
     n0 = O.nll(x, recon.bfloat16().float(), 'bernoulli')
     assert n1.dtype == torch.bfloat16
     close(n1, n0, rtol=1e-2, atol=1.0)
+
+
+# ---- forward + gradient in one pass (vae_nll_elbo_fused): same results as the two-pass form ----
+@pytest.mark.parametrize('nll_type', ['bernoulli', 'gaussian', 'disc_logistic'])
+@pytest.mark.parametrize('shape', [(1, 1, 1, 1), (5, 1, 28, 28), (300, 1, 28, 28), (64, 3, 5, 5), (9, 3, 64, 64)])
+@pytest.mark.parametrize('upstream', ['unit', 'scaled', 'mixed_means'])
+def test_fused_backward_matches_two_pass_and_oracle(nll_type, shape, upstream):
+    from vae_amd import elbo as E
+    torch.manual_seed(sum(shape) + 1)
+    B = shape[0]
+    x, recon = images(*shape, nll_type)
+    kld = torch.rand(B) * 10
+    mi = torch.rand(B)
+    extra = {'a': torch.rand(B)}
+    beta = 0.3
+
+    def objective(r):
+        if upstream == 'unit':
+            return r['loss_mean']                       # loss['loss_mean'].backward(): the training loop's case
+        if upstream == 'scaled':
+            return r['loss_mean'] * 4096.0              # a loss scaler
+        return r['loss_mean'] * 0.5 + r['elbo_mean'] * 2.0 - r['nll_mean'] + r['kld_mean'] * 3.0
+
+    rc, kc = recon.clone().requires_grad_(True), kld.clone().requires_grad_(True)
+    r0 = O.loss_function(O.nll(x, rc, nll_type), kc, beta, mut_info=mi, extra=extra)
+    g0 = torch.autograd.grad(objective(r0), [rc, kc])
+
+    outs = {}
+    for fuse in (True, False):
+        rd, kd = recon.to(DEV).requires_grad_(True), kld.to(DEV).requires_grad_(True)
+        r = E.loss_function(rd, x.to(DEV), kd, nll_type, kl_beta=beta, mut_info=mi.to(DEV),
+                            extra_loss_terms={k: v.to(DEV) for k, v in extra.items()}, fuse_backward=fuse)
+        g = torch.autograd.grad(objective(r), [rd, kd], retain_graph=True)
+        outs[fuse] = (r, g, rd, kd)
+    rf, gf, rd, kd = outs[True]
+    ru, gu, _, _ = outs[False]
+    r64 = None
+    if nll_type != 'bernoulli':
+        rc64 = recon.double().requires_grad_(True)
+        r64 = O.loss_function(O.nll(x.double(), rc64, nll_type), kld.double(), beta, mut_info=mi.double(),
+                              extra={k: v.double() for k, v in extra.items()})
+    for k in ('loss', 'elbo', 'loss_mean', 'elbo_mean', 'nll_mean', 'kld_mean', 'additional_loss_mean', 'mut_info_mean'):
+        close(rf[k], ru[k], rtol=1e-6, atol=1e-6)
+        if nll_type == 'disc_logistic':   # log(cdf difference + 1e-7): the fp32 oracle is itself off where the difference ~ 0
+            close_cond(rf[k].reshape(-1), r0[k].reshape(-1), r64[k].reshape(-1))
+        else:
+            close(rf[k], r0[k], rtol=1e-5, atol=1e-3 if k in ('loss', 'elbo') else 1e-4)
+    close(gf[1], gu[1], rtol=1e-6, atol=0)
+    close(gf[1], g0[1], rtol=1e-5, atol=1e-8)
+    if nll_type == 'bernoulli':
+        # sigmoid(l) - x cancels at x = 1: the fp32 reference itself is only good to an ulp of 1 times the scale
+        tol = 2e-7 * float(g0[0].abs().max())
+        close(gf[0], gu[0], rtol=1e-5, atol=tol)
+        close(gf[0], g0[0], rtol=1e-5, atol=tol)
+    else:   # ill-conditioned in fp32 (see close_cond): as accurate against fp64 as the fp32 oracle
+        (g64,) = torch.autograd.grad(objective(r64), rc64)
+        close_cond(gf[0], g0[0], g64)
+    # a second backward through the same graph (the stored gradient is gone): general kernel, same answer
+    g2 = torch.autograd.grad(objective(rf), [rd, kd])
+    close(g2[0], gu[0], rtol=1e-6, atol=1e-12)
+    # per-sample upstream gradients take the general kernel too
+    r = E.loss_function(rd, x.to(DEV), kd, nll_type, kl_beta=beta, fuse_backward=True)
+    w = torch.randn(B)
+    (gw,) = torch.autograd.grad((r['loss'] * w.to(DEV)).sum() + r['loss_mean'], rd)
+    rw = O.loss_function(O.nll(x, rc, nll_type), kc, beta)
+    (gw0,) = torch.autograd.grad((rw['loss'] * w).sum() + rw['loss_mean'], rc)
+    if nll_type == 'bernoulli':
+        close(gw, gw0, rtol=1e-5, atol=2e-7 * float(gw0.abs().max()))
+
+
+def test_fused_backward_bf16_and_no_grad():
+    from vae_amd import elbo as E
+    torch.manual_seed(4)
+    x, recon = images(64, 1, 28, 28, 'bernoulli')
+    rd = recon.to(DEV).bfloat16().requires_grad_(True)
+    r = E.loss_function(rd, x.to(DEV).bfloat16(), None, 'bernoulli')
+    (g,) = torch.autograd.grad(r['loss_mean'], rd)
+    rc = recon.bfloat16().float().requires_grad_(True)
+    r0 = O.loss_function(O.nll(x, rc, 'bernoulli'), torch.zeros(64))
+    (g0,) = torch.autograd.grad(r0['loss_mean'], rc)
+    close(g, g0, rtol=1e-2, atol=1e-4)
+    with torch.no_grad():    # no graph: the plain forward kernel, no gradient buffer
+        r = E.loss_function(rd, x.to(DEV).bfloat16(), None, 'bernoulli')
+    assert not r['loss_mean'].requires_grad

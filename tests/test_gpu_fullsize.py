@@ -87,9 +87,13 @@ def test_c2_bernoulli_nll_elbo_65536x784():
         close(out1[k], out0[k], rtol=1e-5, atol=1e-5)
     (g1,) = torch.autograd.grad(out1['loss_mean'], rd)
     close(g1, g0, rtol=1e-5, atol=1e-10)
-    # the combine is one float op per output on the kernel's own nll
-    assert torch.equal(out1['elbo'], n1.detach() + kd)
-    assert torch.equal(out1['loss'], n1.detach() + 0.5 * kd)
+    # the combine is one float op per output on the launch's own nll (both the one-pass forward+gradient kernel
+    # and the plain forward kernel)
+    for fuse in (True, False):
+        nn_, ll_, ee_, _ = F_.nll_elbo(xd, rd, 'bernoulli', kld=kd, kl_beta=0.5, fuse_backward=fuse)
+        assert torch.equal(ee_, nn_.detach() + kd)
+        assert torch.equal(ll_, nn_.detach() + 0.5 * kd)
+        close(nn_, n0, rtol=1e-5, atol=1e-3)
     # means vs a double sum of the per-sample outputs
     close(out1['loss_mean'], out1['loss'].double().mean().float(), rtol=1e-6, atol=0)
     # shard invariance

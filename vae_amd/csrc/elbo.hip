@@ -244,7 +244,9 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_fused_kernel(
                 const float e = fast_exp(-fabsf(l));
                 const float r = fast_rcp(1.0f + e);
                 s += fmaxf(l, 0.0f) - l * xv[u][i] + fast_log(1.0f + e);
-                ga[i] = cscale * ((l >= 0.0f ? r : e * r) - xv[u][i]);
+                // sigmoid(l) - x without cancellation at x = 1: for l >= 0 use (1 - x) - (1 - sigmoid) = (1 - x) - e r
+                const float er = e * r;
+                ga[i] = cscale * (l >= 0.0f ? (1.0f - xv[u][i]) - er : er - xv[u][i]);
               }
               if constexpr (NLL == VAE_NLL_GAUSSIAN) {
                 s += nll_gauss(xv[u][i], a[u][i], b[u][i]);

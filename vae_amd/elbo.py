@@ -45,10 +45,13 @@ def reparameterize_multi(reparameterizer, logits, num_samples, force=False, nois
 
 
 def loss_function(recon_x, x, kld, nll_type, kl_beta=1.0, mut_info=None, extra_loss_terms=None, inv_count=None,
-                  nll_given=None):
+                  nll_given=None, fuse_backward=True):
     """The loss dict of abstract_vae.py:377-388 from tensors.  One fused launch (+ a 1-block finalize)
     when the NLL comes from (x, recon_x); a LIST of decoder outputs in `recon_x` is the K > 1 case
-    (:347-354: nll averaged over the list, x read once); `nll_given` [B] uses the combine kernel."""
+    (:347-354: nll averaged over the list, x read once); `nll_given` [B] uses the combine kernel.
+    `fuse_backward` (K == 1, recon_x requiring grad): d(loss_mean)/d(recon_x) is formed by the forward launch
+    itself, so a training step reads x and recon_x once, not twice; any other backward use falls back to the
+    general backward kernel with identical results."""
     add = None
     if extra_loss_terms:
         vals = list(extra_loss_terms.values())
@@ -58,7 +61,7 @@ def loss_function(recon_x, x, kld, nll_type, kl_beta=1.0, mut_info=None, extra_l
                                                  kl_beta=kl_beta, inv_count=inv_count)
     elif nll_given is None:
         _, loss, elbo, means = F_.nll_elbo(x, recon_x, nll_type, kld=kld, add=add, mi=mut_info, kl_beta=kl_beta,
-                                           inv_count=inv_count)
+                                           inv_count=inv_count, fuse_backward=fuse_backward)
     else:
         loss, elbo, means = F_.elbo_combine(nll_given, kld=kld, add=add, mi=mut_info, kl_beta=kl_beta,
                                             inv_count=inv_count)

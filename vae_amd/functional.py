@@ -197,6 +197,59 @@ class _NllElbo(torch.autograd.Function):
         return None, grecon, gkld, gadd, gmi, None, None, None, None
 
 
+class _NllElboFused(torch.autograd.Function):
+    """nll + ELBO combine with d(loss_mean)/d(recon) produced by the SAME pass over x and recon.  backward():
+    only mean gradients arriving (loss_mean.backward(), the training loop's case) -> the stored gradient is
+    handed out after a device-side rescale that is a no-op for a unit upstream gradient; any per-sample
+    gradient (nll / loss / elbo [B]) -> the general backward kernel recomputes from x and recon."""
+
+    @staticmethod
+    def forward(ctx, x, recon, kld, add, mi, nll_code, kl_beta, inv_count):
+        ctx.set_materialize_grads(False)
+        dev = check_device(x, recon, kld, add, mi)
+        B, D = x.shape
+        nll = torch.empty((B,), dtype=x.dtype, device=dev)
+        loss, elbo = torch.empty_like(nll), torch.empty_like(nll)
+        means = torch.zeros((6,), dtype=torch.float32, device=dev)
+        grecon = torch.empty_like(recon)
+        with _Guard(dev):
+            call('vae_nll_elbo_fused', ptr(x), ptr(recon), nll_code, ptr(kld), ptr(add), ptr(mi), kl_beta, inv_count,
+                 1.0, ptr(nll), ptr(loss), ptr(elbo), ptr(means), ptr(workspace(dev)), ptr(grecon), B, D,
+                 dtype_code(x), stream_ptr(dev))
+        ctx.save_for_backward(x, recon)
+        ctx.grecon = grecon
+        ctx.cfg = (nll_code, kl_beta, inv_count, kld is not None, add is not None, mi is not None)
+        return nll, loss, elbo, means
+
+    @staticmethod
+    def backward(ctx, gnll, gloss, gelbo, gmeans):
+        x, recon = ctx.saved_tensors
+        nll_code, kl_beta, inv_count, has_kld, has_add, has_mi = ctx.cfg
+        dev = x.device
+        B, D = x.shape
+        gnll, gloss, gelbo = _dense(gnll), _dense(gloss), _dense(gelbo)
+        gmeans = None if gmeans is None else gmeans.contiguous().float()
+        new = lambda: torch.empty((B,), dtype=x.dtype, device=dev)
+        gkld = new() if has_kld and ctx.needs_input_grad[2] else None
+        gadd = new() if has_add and ctx.needs_input_grad[3] else None
+        gmi = new() if has_mi and ctx.needs_input_grad[4] else None
+        grecon = ctx.grecon
+        ctx.grecon = None
+        with _Guard(dev):
+            if gnll is None and gloss is None and gelbo is None and gmeans is not None and grecon is not None:
+                call('vae_nll_fused_grad_finish', ptr(grecon), ptr(gmeans), grecon.numel(), dtype_code(x),
+                     stream_ptr(dev))
+                if gkld is not None or gadd is not None or gmi is not None:
+                    call('vae_elbo_combine_bwd', None, None, ptr(gmeans), kl_beta, inv_count, None, ptr(gkld),
+                         ptr(gadd), ptr(gmi), B, dtype_code(x), stream_ptr(dev))
+            else:
+                grecon = torch.empty_like(recon)
+                call('vae_nll_elbo_bwd', ptr(x), ptr(recon), nll_code, ptr(gnll), ptr(gloss), ptr(gelbo), ptr(gmeans),
+                     kl_beta, inv_count, ptr(grecon), ptr(gkld), ptr(gadd), ptr(gmi), B, D, dtype_code(x),
+                     stream_ptr(dev))
+        return None, grecon, gkld, gadd, gmi, None, None, None
+
+
 def _flat_pixels(x, recon, nll_type):
     code = _lib.NLL_TYPES[nll_type.strip().lower()]
     B = x.shape[0]
@@ -216,12 +269,17 @@ def nll(x, recon_x, nll_type):
     return _NllElbo.apply(xf, rf, None, None, None, code, 0.0, 0.0, False)[0]
 
 
-def nll_elbo(x, recon_x, nll_type, kld=None, add=None, mi=None, kl_beta=1.0, inv_count=None):
+def nll_elbo(x, recon_x, nll_type, kld=None, add=None, mi=None, kl_beta=1.0, inv_count=None, fuse_backward=False):
     """Fused nll + ELBO combine: returns (nll, loss, elbo) [B] and means float32[6]
-    ordered (loss, elbo, nll, kld, additional, mut_info).  abstract_vae.py:344-388 with K == 1."""
+    ordered (loss, elbo, nll, kld, additional, mut_info).  abstract_vae.py:344-388 with K == 1.
+    `fuse_backward`: also form d(loss_mean)/d(recon) in the same pass (one read of x and recon per training
+    step instead of two); results are identical, the gradient buffer is simply allocated a step earlier."""
     code, xf, rf = _flat_pixels(x, recon_x, nll_type)
     if inv_count is None:
         inv_count = 1.0 / max(xf.shape[0], 1)
+    if fuse_backward and rf.requires_grad and torch.is_grad_enabled() and xf.shape[0] > 0:
+        out = _NllElboFused.apply(xf, rf, _dense(kld), _dense(add), _dense(mi), code, float(kl_beta), float(inv_count))
+        return out
     return _NllElbo.apply(xf, rf, _dense(kld), _dense(add), _dense(mi), code, float(kl_beta), float(inv_count), True)
 
 
