@@ -39,11 +39,12 @@ B_PER_GPU, L, C, H, W = 65536, 512, 1, 28, 28
 D = C * H * W
 
 
-def algorithmic_bytes(B):
-    """SURVEY 8(d), fp32, per launch."""
+def algorithmic_bytes(B, philox=False):
+    """SURVEY 8(d), fp32, per launch (the noise terms drop out with in-kernel Philox)."""
+    nz = 0 if philox else 4 * L
     return {
-        'gauss_reparam_kl_fwd': (16 * L + 4) * B,   # logits 8L + noise 4L + z 4L + kl 4
-        'gauss_reparam_kl_bwd': (24 * L + 4) * B,   # logits 8L + noise 4L + gz 4L + gkl 4 + glogits 8L
+        'gauss_reparam_kl_fwd': (12 * L + nz + 4) * B,   # logits 8L + noise 4L + z 4L + kl 4
+        'gauss_reparam_kl_bwd': (20 * L + nz + 4) * B,   # logits 8L + noise 4L + gz 4L + gkl 4 + glogits 8L
         'nll_elbo_fwd': (8 * D + 12) * B,           # x 4D + recon 4D + kld 4 + loss, elbo 8
         'nll_elbo_bwd': (12 * D) * B,               # x 4D + recon 4D + grecon 4D
         'nll_elbo_fused': (12 * D + 12) * B,        # x 4D + recon 4D + grecon 4D + kld 4 + loss, elbo 8
@@ -82,6 +83,8 @@ def main():
     ap.add_argument('--batch', type=int, default=B_PER_GPU, help='samples per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--two-pass', action='store_true', help='separate NLL forward and backward kernels')
+    ap.add_argument('--noise', choices=['injected', 'philox'], default='injected',
+                    help='injected: eps read from HBM (the parity-test form); philox: drawn inside the kernels')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -148,17 +151,21 @@ def main():
     row0 = rank * B
 
     fused = not args.two_pass
+    philox = args.noise == 'philox'
+    pnoise = None if philox else ptr(noise)
     names = ['gauss_reparam_kl_fwd', 'nll_elbo_fused', 'grad_finish', 'gauss_reparam_kl_bwd'] if fused else \
         ['gauss_reparam_kl_fwd', 'nll_elbo_fwd', 'nll_elbo_bwd', 'gauss_reparam_kl_bwd']
     pmeans = ctypes_off(scalars, 6)
+
+    step_no = [1]   # Philox call offset: a fresh draw every step, the same one in that step's backward
 
     def step(ev=None):
         def mark(i):
             if ev is not None:
                 ev[i].record()
         mark(0)
-        call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, ptr(noise), ptr(z), L, ptr(logvar), ptr(kl), pmeans,
-             ptr(ws), B, L, 1e-6, mean_scale, 1, 0, 0, row0, 0, st)
+        call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, pnoise, ptr(z), L, ptr(logvar), ptr(kl), pmeans,
+             ptr(ws), B, L, 1e-6, mean_scale, 1, 1234, step_no[0], row0, 0, st)
         mark(1)
         if fused:
             call('vae_nll_elbo_fused', ptr(x), ptr(recon), 0, ptr(kl), None, None, 1.0, inv_count, 1.0, ptr(nll),
@@ -177,9 +184,10 @@ def main():
             call('vae_nll_elbo_bwd', ptr(x), ptr(recon), 0, None, None, None, ptr(gmeans), 1.0, inv_count,
                  ptr(grecon), ptr(gkld), None, None, B, D, 0, st)
         mark(4)
-        call('vae_gauss_reparam_kl_bwd', ptr(logits), 2 * L, ptr(noise), ptr(gz), L, None, ptr(gkld), None,
-             ptr(glogits), 2 * L, B, L, 1e-6, mean_scale, 1, 0, 0, row0, 0, st)
+        call('vae_gauss_reparam_kl_bwd', ptr(logits), 2 * L, pnoise, ptr(gz), L, None, ptr(gkld), None,
+             ptr(glogits), 2 * L, B, L, 1e-6, mean_scale, 1, 1234, step_no[0], row0, 0, st)
         mark(5)
+        step_no[0] += 1
 
     for _ in range(args.warmup):
         step()
@@ -241,7 +249,7 @@ def main():
                        'what': 'IsotropicGaussian.forward + .kl + elbo.loss_function + autograd backward, 20 steps'}
 
     if rank == 0:
-        ab = algorithmic_bytes(B)
+        ab = algorithmic_bytes(B, philox)
         kernels = {}
         for n in names:
             gbs = ab[n] / (dur_ms[n] * 1e-3) / 1e9
@@ -276,7 +284,7 @@ def main():
                                    'Bernoulli NLL; step = reparam+KL fwd, NLL+ELBO fwd, both backward (%s)'
                                    % (B, 'NLL forward and gradient in one pass' if fused else 'two-pass NLL'),
                        'global_batch': B * world, 'latent': L, 'pixels': D, 'parallelism': 'dp%d' % world,
-                       'noise': 'injected (resident in HBM)'},
+                       'noise': 'in-kernel Philox4x32-10' if philox else 'injected (resident in HBM)'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': kernels[dom]['achieved_GBs'],
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kernels[dom]['frac'], 'traffic': traffic},
             'kernels': kernels,
