@@ -152,7 +152,7 @@ def main():
 
     fused = not args.two_pass
     philox = args.noise == 'philox'
-    pnoise = None if philox else ptr(noise)
+    noise_arg = [None if philox else ptr(noise)]   # None: the kernels draw Philox noise themselves
     names = ['gauss_reparam_kl_fwd', 'nll_elbo_fused', 'grad_finish', 'gauss_reparam_kl_bwd'] if fused else \
         ['gauss_reparam_kl_fwd', 'nll_elbo_fwd', 'nll_elbo_bwd', 'gauss_reparam_kl_bwd']
     pmeans = ctypes_off(scalars, 6)
@@ -164,7 +164,7 @@ def main():
             if ev is not None:
                 ev[i].record()
         mark(0)
-        call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, pnoise, ptr(z), L, ptr(logvar), ptr(kl), pmeans,
+        call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, noise_arg[0], ptr(z), L, ptr(logvar), ptr(kl), pmeans,
              ptr(ws), B, L, 1e-6, mean_scale, 1, 1234, step_no[0], row0, 0, st)
         mark(1)
         if fused:
@@ -184,7 +184,7 @@ def main():
             call('vae_nll_elbo_bwd', ptr(x), ptr(recon), 0, None, None, None, ptr(gmeans), 1.0, inv_count,
                  ptr(grecon), ptr(gkld), None, None, B, D, 0, st)
         mark(4)
-        call('vae_gauss_reparam_kl_bwd', ptr(logits), 2 * L, pnoise, ptr(gz), L, None, ptr(gkld), None,
+        call('vae_gauss_reparam_kl_bwd', ptr(logits), 2 * L, noise_arg[0], ptr(gz), L, None, ptr(gkld), None,
              ptr(glogits), 2 * L, B, L, 1e-6, mean_scale, 1, 1234, step_no[0], row0, 0, st)
         mark(5)
         step_no[0] += 1
@@ -216,6 +216,29 @@ def main():
     sanity = float(scalars[0].item())
     if not (sanity == sanity):
         raise SystemExit('bench: loss_mean is NaN')
+
+    # the production form of the same step (the module classes' default): eps drawn inside the kernels from
+    # Philox4x32-10 instead of read from HBM -- reported beside the main figure, never as `value`
+    philox_variant = None
+    if world == 1 and not philox:
+        noise_arg[0] = None
+        for _ in range(args.warmup):
+            step()
+        ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            step(ev2[k])
+        torch.cuda.synchronize(dev)
+        dt2 = time.perf_counter() - t1
+        noise_arg[0] = ptr(noise)
+        ab2 = algorithmic_bytes(B, True)
+        philox_variant = {'value': B * args.steps / dt2, 'unit': 'samples/s', 'ms_per_step': dt2 / args.steps * 1e3,
+                          'kernels': {}}
+        for n, (a, b) in seg.items():
+            ms = sum(e[a].elapsed_time(e[b]) for e in ev2) / args.steps
+            philox_variant['kernels'][n] = {'avg_ms': round(ms, 5), 'algorithmic_bytes': ab2[n],
+                                            'frac': round(ab2[n] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
     # the same step through the drop-in classes (autograd Functions, torch allocator): not the timed region,
     # reported beside it so the cost of the Python boundary is visible
@@ -293,6 +316,7 @@ def main():
                          'frac': round(total_bytes / (ksum * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             'loss_mean': sanity,
             'module_path': module_path,
+            'philox_variant': philox_variant,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

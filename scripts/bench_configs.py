@@ -197,6 +197,37 @@ def nll(B, D, code, name, dtype=torch.float32):
     timeit('nll_elbo_bwd', cfg, lambda: call('vae_nll_elbo_bwd', ptr(x), ptr(recon), code, None, None, None, ptr(gm), 1.0, 1.0 / B, ptr(gr), ptr(gk), None, None, B, D, dc, st), B * (D + 2 * R) * es)
 
 
+def nll_fused(B, D, code, name):
+    R = D if code == 0 else 2 * D
+    x = (T(B, D, kind='rand') * 255).floor().div(255) if code else (T(B, D, kind='rand') < 0.13).float()
+    recon, kld = T(B, R), T(B, kind='rand')
+    n, lo, el, gr = T(B, kind='e'), T(B, kind='e'), T(B, kind='e'), T(B, R, kind='e')
+    means, gm = torch.zeros(6, device=dev), torch.zeros(6, device=dev)
+    gm[0] = 1
+    cfg = 'B=%d D=%d %s f32 (fwd + gradient, one pass)' % (B, D, name)
+    timeit('nll_elbo_fused', cfg, lambda: call('vae_nll_elbo_fused', ptr(x), ptr(recon), code, ptr(kld), None, None, 1.0, 1.0 / B, 1.0, ptr(n), ptr(lo), ptr(el), ptr(means), ptr(ws), ptr(gr), B, D, 0, st), B * ((D + 2 * R) * 4 + 12))
+    timeit('nll_fused_grad_finish', cfg, lambda: call('vae_nll_fused_grad_finish', ptr(gr), ptr(gm), B * R, 0, st), 12)
+
+
+def flowtail(B, F):
+    """One MAF block's tails: MADE (x, [m|a] -> u, logdet) then BatchNormFlow + Reverse (train)."""
+    x, ma, gu, gld = T(B, F), T(B, 2 * F) * 0.3, T(B, F), T(B)
+    u, ld, gx, gma = T(B, F, kind='e'), T(B, kind='e'), T(B, F, kind='e'), T(B, 2 * F, kind='e')
+    off = lambda t, n: ctypes.c_void_p(t.data_ptr() + 4 * n)
+    cfg = 'B=%d F=%d f32' % (B, F)
+    timeit('made_tail_fwd', cfg, lambda: call('vae_made_tail_fwd', ptr(x), F, ptr(ma), 2 * F, off(ma, F), 2 * F, ptr(u), None, ptr(ld), B, F, 0, 0, st), B * (16 * F + 4))
+    timeit('made_tail_bwd', cfg, lambda: call('vae_made_tail_bwd', ptr(u), off(ma, F), 2 * F, ptr(gu), ptr(gld), ptr(gx), ptr(gma), 2 * F, off(gma, F), 2 * F, B, F, 0, 0, st), B * (24 * F + 4))
+    lg, beta = T(F) * 0.1, T(F)
+    stats = torch.empty(_lib.load().vae_bnflow_stats_floats(F), device=dev)
+    y, ld2 = T(B, F, kind='e'), T(B, kind='e')
+    timeit('bnflow_fwd (stats+apply+reverse)', cfg, lambda: call('vae_bnflow_fwd', ptr(u), ptr(lg), ptr(beta), None, None, ptr(stats), ptr(y), ptr(ld), ptr(ld2), B, F, 1e-5, 1, 1, 0, st), B * (12 * F + 8))
+    timeit('bnflow_bwd (stats+apply)', cfg, lambda: call('vae_bnflow_bwd', ptr(u), ptr(gu), ptr(gld), ptr(stats), ptr(gx), B, F, 1, 1, 0, st), B * (20 * F + 4))
+    s_raw, t_raw, mask = T(B, F) * 0.3, T(B, F), (torch.arange(F, device=dev) % 2).float()
+    gs, gt = T(B, F, kind='e'), T(B, F, kind='e')
+    timeit('coupling_tail_fwd', cfg, lambda: call('vae_coupling_tail_fwd', ptr(x), ptr(s_raw), ptr(t_raw), ptr(mask), ptr(y), None, ptr(ld), B, F, 0, st), B * (16 * F + 4))
+    timeit('coupling_tail_bwd', cfg, lambda: call('vae_coupling_tail_bwd', ptr(x), ptr(s_raw), ptr(mask), ptr(gu), ptr(gld), ptr(gx), ptr(gs), ptr(gt), B, F, 0, st), B * (24 * F + 4))
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--json', default=None)
@@ -209,6 +240,7 @@ if __name__ == '__main__':
     for B in (4096, 16384, 65536):
         nll(B, 784, 0, 'bernoulli')
     nll(65536, 784, 0, 'bernoulli', dtype=torch.bfloat16)
+    nll_fused(65536, 784, 0, 'bernoulli')
     print('== C3: Gumbel-softmax / Concat')
     for K in (32, 256, 1024):
         gumbel(65536, K)
@@ -219,6 +251,11 @@ if __name__ == '__main__':
     nll(8192, 12288, 2, 'disc_logistic')
     nll(8192, 12288, 1, 'gaussian')
     flow(65536, 512)
+    nll_fused(8192, 12288, 2, 'disc_logistic')
+    nll_fused(8192, 12288, 1, 'gaussian')
+    print('== flow-layer tails (one MAF / RealNVP block)')
+    flowtail(65536, 512)
+    flowtail(65536, 64)
     print('== C5: VRNN per-step pair (B per step) and the time-batched loss (T*B rows)')
     gauss(16384, 128)
     gauss_pair(16384, 128)
