@@ -293,7 +293,8 @@ int vae_coupling_tail_bwd(const void* x, const void* s_raw, const float* mask, c
  *   logdet = sum_f (log_gamma - 0.5 log var).  log_gamma, beta, mean_in, var_in: F floats.
  *   stats: caller-owned fp32 scratch of vae_bnflow_stats_floats(F) floats, kept for the backward:
  *   [0,F) mean | [F,2F) var | [2F,3F) 1/sqrt(var) | [3F,4F) scale | [4F,5F) beta | [5F,6F) logdet terms |
- *   (backward) [6F,7F) sum_b gy = d beta | [7F,8F) sum_b gy*x_hat | [8F] sum_b glogdet | block partials.
+ *   (backward) [6F,7F) sum_b gy = d beta | [7F,8F) sum_b gy*x_hat | [8F] sum_b glogdet | two [F] vectors of
+ *   backward constants | block partials.
  *   The caller updates the running statistics from stats[0,2F) (:240-246) and forms
  *   d log_gamma = exp(log_gamma) * stats[7F..8F) + stats[8F].  F <= VAE_MAX_BN_ROW.               */
 size_t vae_bnflow_stats_floats(int64_t F);

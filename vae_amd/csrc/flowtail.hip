@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void coupling_tail_bwd_kernel(
 // `rev`: gy / y live in reversed column order (the fused Reverse).
 // ---------------------------------------------------------------------------------------------
 constexpr int kBnChunks = 4;                    // vectors per lane: F <= 4 * G * V
-constexpr int kBnGrid = 256;                    // one block per CU; partials = 256 * 2F floats
+constexpr int kBnGrid = 1024;                   // 4 blocks per CU; partials = 1024 * (2F + 1) floats
 
 template <typename T, int V>
 __device__ __forceinline__ void load_vec_rev(const T* __restrict__ rowp, int j, int nvec, bool rev, float (&out)[V]) {
@@ -243,69 +243,82 @@ __device__ __forceinline__ void load_vec_rev(const T* __restrict__ rowp, int j, 
   }
 }
 
-template <typename T, int V>
+// NJ column-vectors per lane (1, 2 or 4), R row tiles in flight per iteration (all loads issued up front).
+template <typename T, int V, int NJ, int R>
 __global__ __launch_bounds__(kBlock) void bn_colstats_kernel(
     const T* __restrict__ x, const T* __restrict__ gy, const T* __restrict__ gld, const float* __restrict__ mean,
     const float* __restrict__ rstd, float* __restrict__ part, int64_t B, int F, int mode, int rev, int G,
     int64_t tiles) {
-  __shared__ float lds[kBnChunks * V * kBlock];   // [slot][tid], slot < kBnChunks*V; one statistic at a time
+  __shared__ float lds[NJ * V * kBlock];   // [slot][tid], slot < NJ*V; one statistic at a time
   const int rpb = kBlock / G;
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = F / V;
-  float a1[kBnChunks][V], a2[kBnChunks][V], c0[kBnChunks][V], c1[kBnChunks][V];
+  float a1[NJ][V], a2[NJ][V], c0[NJ][V], c1[NJ][V];
+  int jc[NJ];
+  bool jv[NJ];
   float extra = 0.f;
 #pragma unroll
-  for (int k = 0; k < kBnChunks; ++k) {
+  for (int k = 0; k < NJ; ++k) {
     const int j = sub + k * G;
+    jv[k] = j < nvec;
+    jc[k] = jv[k] ? j : nvec - 1;
 #pragma unroll
-    for (int i = 0; i < V; ++i) { a1[k][i] = 0.f; a2[k][i] = 0.f; c0[k][i] = 0.f; c1[k][i] = 1.f; }
-    if (j < nvec) {
-      if (mode == 0) {
-        load_vec<T, V, false>(x + (int64_t)j * V, c0[k]);          // shift: the first row
-      } else {
-        load_f32<V>(mean + (int64_t)j * V, c0[k]);
-        load_f32<V>(rstd + (int64_t)j * V, c1[k]);
-      }
+    for (int i = 0; i < V; ++i) { a1[k][i] = 0.f; a2[k][i] = 0.f; c1[k][i] = 1.f; }
+    if (mode == 0) {
+      load_vec<T, V, false>(x + (int64_t)jc[k] * V, c0[k]);          // shift: the first row
+    } else {
+      load_f32<V>(mean + (int64_t)jc[k] * V, c0[k]);
+      load_f32<V>(rstd + (int64_t)jc[k] * V, c1[k]);
     }
   }
-  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-    const int64_t row = t * rpb + rloc;
-    if (row >= B) continue;
-    if (mode == 1 && gld && sub == 0) extra += to_f32(gld[row]);
+  for (int64_t t0 = blockIdx.x; t0 < tiles; t0 += (int64_t)gridDim.x * R) {
+    float xv[R][NJ][V], gv[R][NJ][V];
+    bool rv[R];
 #pragma unroll
-    for (int k = 0; k < kBnChunks; ++k) {
-      const int j = sub + k * G;
-      if (j < nvec) {
-        float xv[V], gv[V];
-        load_vec<T, V>(x + row * F + (int64_t)j * V, xv);
-        if (mode == 1) load_vec_rev<T, V>(gy + row * F, j, nvec, rev != 0, gv);
+    for (int r = 0; r < R; ++r) {
+      const int64_t t = t0 + (int64_t)r * gridDim.x;
+      const int64_t row = t * rpb + rloc;
+      rv[r] = t < tiles && row < B;
+      const int64_t rowc = rv[r] ? row : 0;
+#pragma unroll
+      for (int k = 0; k < NJ; ++k) {
+        load_vec<T, V>(x + rowc * F + (int64_t)jc[k] * V, xv[r][k]);
+        if (mode == 1) load_vec_rev<T, V>(gy + rowc * F, jc[k], nvec, rev != 0, gv[r][k]);
+      }
+      if (mode == 1 && gld && sub == 0 && rv[r]) extra += to_f32(gld[row]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int k = 0; k < NJ; ++k) {
+        const bool ok = rv[r] && jv[k];
 #pragma unroll
         for (int i = 0; i < V; ++i) {
           if (mode == 0) {
-            const float d = xv[i] - c0[k][i];
+            const float d = ok ? xv[r][k][i] - c0[k][i] : 0.f;
             a1[k][i] += d;
             a2[k][i] += d * d;
           } else {
-            a1[k][i] += gv[i];
-            a2[k][i] += gv[i] * ((xv[i] - c0[k][i]) * c1[k][i]);
+            const float g = ok ? gv[r][k][i] : 0.f;
+            a1[k][i] += g;
+            a2[k][i] += g * ((xv[r][k][i] - c0[k][i]) * c1[k][i]);
           }
         }
       }
-    }
   }
-  // fold the rpb rows of the block (k-major LDS: conflict-free), then one partial per block
+  // fold the rpb rows of the block (slot-major LDS: conflict-free), then one partial per block
   float* mypart = part + (size_t)blockIdx.x * (2 * (size_t)F + 1);
   if (rpb > 1) {
     for (int st = 0; st < 2; ++st) {
       if (st) __syncthreads();   // the readers of the first statistic are done
 #pragma unroll
-      for (int k = 0; k < kBnChunks; ++k)
+      for (int k = 0; k < NJ; ++k)
 #pragma unroll
         for (int i = 0; i < V; ++i) lds[(k * V + i) * kBlock + threadIdx.x] = st ? a2[k][i] : a1[k][i];
       __syncthreads();
       // thread (rloc, sub) folds the slots q = rloc, rloc + rpb, ... of lane `sub`
-      for (int q = rloc; q < kBnChunks * V; q += rpb) {
+      for (int q = rloc; q < NJ * V; q += rpb) {
         const int k = q / V, i = q % V;
         const int j = sub + k * G;
         if (j < nvec) {
@@ -317,13 +330,12 @@ __global__ __launch_bounds__(kBlock) void bn_colstats_kernel(
     }
   } else {
 #pragma unroll
-    for (int k = 0; k < kBnChunks; ++k) {
-      const int j = sub + k * G;
-      if (j < nvec) {
+    for (int k = 0; k < NJ; ++k) {
+      if (jv[k]) {
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-          mypart[(size_t)j * V + i] = a1[k][i];
-          mypart[(size_t)F + (size_t)j * V + i] = a2[k][i];
+          mypart[(size_t)jc[k] * V + i] = a1[k][i];
+          mypart[(size_t)F + (size_t)jc[k] * V + i] = a2[k][i];
         }
       }
     }
@@ -336,146 +348,126 @@ __global__ __launch_bounds__(kBlock) void bn_colstats_kernel(
   if (threadIdx.x == 0) mypart[2 * (size_t)F] = ex[0] + ex[1] + ex[2] + ex[3];
 }
 
-// Second step: 32 columns x 8 partial-groups per block; block order, double.
+// Second step: 8 columns x 32 partial-groups per block; block order, double.
 //   mode 0: mean = c + S1/B, var = S2/B - (S1/B)^2 + eps; then the per-column constants of the apply:
-//           scale = exp(lg) / sqrt(var), shift = beta, ldc = lg - 0.5 log var, rstd
-//   mode 1: out1 = S1 (sum gy), out2 = S2 (sum gy*x_hat), extra_out[0] = sum gld (block 0)
+//           rstd, scale = exp(lg) * rstd, beta, ldc = lg - 0.5 log var
+//   mode 1: S1 = sum gy (= d beta), S2 = sum gy*x_hat, GLD = sum gld, and the backward apply's constants
+//           k1 = scale*S1/B, K = rstd*(scale*S2/B + GLD*rstd/B)   (training; eval: both 0)
+constexpr int kFinCols = 8, kFinGroups = kBlock / kFinCols;
 __global__ __launch_bounds__(kBlock) void bn_finalize_kernel(
     const float* __restrict__ part, int nparts, const void* __restrict__ x0, int x_is_bf16, const float* __restrict__ lg,
-    const float* __restrict__ beta, float* __restrict__ o_mean, float* __restrict__ o_var, float* __restrict__ o_scale,
-    float* __restrict__ o_shift, float* __restrict__ o_ldc, float* __restrict__ o_rstd, float* __restrict__ extra_out,
-    int64_t B, int F, float eps, int mode) {
-  __shared__ double l1[8][32], l2[8][32];
-  const int cl = threadIdx.x & 31, pg = threadIdx.x >> 5;
-  const int col = blockIdx.x * 32 + cl;
+    const float* __restrict__ beta, float* __restrict__ stats, int64_t B, int F, float eps, int mode, int training) {
+  __shared__ double l1[kFinGroups][kFinCols], l2[kFinGroups][kFinCols];
+  __shared__ double lex[kBlock / 64];
+  const int cl = threadIdx.x % kFinCols, pg = threadIdx.x / kFinCols;
+  const int col = blockIdx.x * kFinCols + cl;
   const size_t pstride = 2 * (size_t)F + 1;
+  float *o_mean = stats, *o_var = stats + F, *o_rstd = stats + 2 * (size_t)F, *o_scale = stats + 3 * (size_t)F,
+        *o_beta = stats + 4 * (size_t)F, *o_ldc = stats + 5 * (size_t)F, *o_s1 = stats + 6 * (size_t)F,
+        *o_s2 = stats + 7 * (size_t)F, *o_gsum = stats + 8 * (size_t)F, *o_k1 = stats + 8 * (size_t)F + 4,
+        *o_K = stats + 9 * (size_t)F + 4;
   double s1 = 0.0, s2 = 0.0;
   if (col < F) {
-    for (int p = pg; p < nparts; p += 8) {
+#pragma unroll 4
+    for (int p = pg; p < nparts; p += kFinGroups) {
       s1 += (double)part[p * pstride + col];
       s2 += (double)part[p * pstride + F + col];
     }
   }
   l1[pg][cl] = s1;
   l2[pg][cl] = s2;
+  double gsum = 0.0;
+  if (mode == 1) {   // every block needs GLD: thread-strided, then wave + LDS fold (fixed order)
+    double e = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += kBlock) e += (double)part[p * pstride + 2 * (size_t)F];
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+    if ((threadIdx.x & 63) == 0) lex[threadIdx.x >> 6] = e;
+  }
   __syncthreads();
+  if (mode == 1) gsum = lex[0] + lex[1] + lex[2] + lex[3];
   if (pg == 0 && col < F) {
     s1 = 0.0; s2 = 0.0;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) { s1 += l1[g][cl]; s2 += l2[g][cl]; }
+    for (int g = 0; g < kFinGroups; ++g) { s1 += l1[g][cl]; s2 += l2[g][cl]; }
     if (mode == 0) {
       const float c = x_is_bf16 ? to_f32(((const bf16_t*)x0)[col]) : ((const float*)x0)[col];
       const double m1 = s1 / (double)B;
       const float mean = (float)((double)c + m1);
       const float var = (float)(s2 / (double)B - m1 * m1) + eps;
       const float r = 1.0f / sqrtf(var);
-      const float sc = expf(lg[col]) * r;
       o_mean[col] = mean;
       o_var[col] = var;
       o_rstd[col] = r;
-      o_scale[col] = sc;
-      o_shift[col] = beta[col];
+      o_scale[col] = expf(lg[col]) * r;
+      o_beta[col] = beta[col];
       o_ldc[col] = lg[col] - 0.5f * logf(var);
     } else {
-      o_mean[col] = (float)s1;
-      o_var[col] = (float)s2;
+      o_s1[col] = (float)s1;
+      o_s2[col] = (float)s2;
+      const double inv_b = 1.0 / (double)B;
+      const double sc = (double)o_scale[col], r = (double)o_rstd[col];
+      o_k1[col] = training ? (float)(sc * s1 * inv_b) : 0.f;
+      o_K[col] = training ? (float)(r * (sc * s2 * inv_b + gsum * inv_b * r)) : 0.f;
     }
   }
-  if (mode == 1 && blockIdx.x == 0 && threadIdx.x == 0) {
-    double e = 0.0;
-    for (int p = 0; p < nparts; ++p) e += (double)part[p * pstride + 2 * (size_t)F];
-    extra_out[0] = (float)e;
-  }
+  if (mode == 1 && blockIdx.x == 0 && threadIdx.x == 0) o_gsum[0] = (float)gsum;
 }
 
 // eval mode / explicit statistics: the per-column constants from given mean / var vectors
 __global__ __launch_bounds__(kBlock) void bn_prepare_kernel(const float* __restrict__ mean, const float* __restrict__ var,
                                                            const float* __restrict__ lg, const float* __restrict__ beta,
-                                                           float* __restrict__ o_scale, float* __restrict__ o_shift,
-                                                           float* __restrict__ o_ldc, float* __restrict__ o_rstd, int F) {
+                                                           float* __restrict__ stats, int F) {
   const int col = blockIdx.x * kBlock + threadIdx.x;
   if (col >= F) return;
   const float r = 1.0f / sqrtf(var[col]);
-  const float sc = expf(lg[col]) * r;
-  o_rstd[col] = r;
-  o_scale[col] = sc;
-  o_shift[col] = beta[col];
-  o_ldc[col] = lg[col] - 0.5f * logf(var[col]);
+  stats[col] = mean[col];
+  stats[(size_t)F + col] = var[col];
+  stats[2 * (size_t)F + col] = r;
+  stats[3 * (size_t)F + col] = expf(lg[col]) * r;
+  stats[4 * (size_t)F + col] = beta[col];
+  stats[5 * (size_t)F + col] = lg[col] - 0.5f * logf(var[col]);
+}
+
+// sum of F floats, the same value (same order) in every thread of every block
+__device__ __forceinline__ float block_sum_vector(const float* __restrict__ v, int F) {
+  __shared__ float bs[kBlock / 64];
+  float s = 0.f;
+  for (int j = threadIdx.x; j < F; j += kBlock) s += v[j];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) bs[threadIdx.x >> 6] = s;
+  __syncthreads();
+  return (bs[0] + bs[1]) + (bs[2] + bs[3]);
 }
 
 // y[b, p(j)] = (x - mean_j)*scale_j + beta_j (the subtraction first, as the reference: x*scale + shift would
-// cancel catastrophically when |mean| >> std);  logdet_out[b] = logdet_in[b] + sum_j ldc_j
-template <typename T, int V, int U>
+// cancel catastrophically when |mean| >> std);  logdet_out[b] = logdet_in[b] + sum_j ldc_j.
+// HOIST (the row fits U vectors per lane): a lane always owns the same columns, so their constants are loaded
+// once and stay in registers while the block walks its row tiles.
+template <typename T, int V, int U, bool HOIST>
 __global__ __launch_bounds__(kBlock) void bn_apply_fwd_kernel(
     const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ scale,
-    const float* __restrict__ shift, const float* __restrict__ ldc, T* __restrict__ y, const T* __restrict__ ld_in, T* __restrict__ ld_out, int64_t B,
-    int F, int rev, int G, int64_t tiles) {
+    const float* __restrict__ shift, const float* __restrict__ ldc, T* __restrict__ y, const T* __restrict__ ld_in,
+    T* __restrict__ ld_out, int64_t B, int F, int rev, int G, int64_t tiles) {
   const int rpb = kBlock / G;
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = F / V;
-  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-    const int64_t row = t * rpb + rloc;
-    float s = 0.f;
-    if (row < B) {
-      for (int j0 = sub; j0 < nvec; j0 += G * U) {
-        float xv[U][V], mu[U][V], sc[U][V], sh[U][V], lc[U][V];
-        load_chunk<T, V, U>(x + row * F, j0, G, nvec, xv);
-        load_f32_chunk<V, U>(mean, j0, G, nvec, mu);
-        load_f32_chunk<V, U>(scale, j0, G, nvec, sc);
-        load_f32_chunk<V, U>(shift, j0, G, nvec, sh);
-        load_f32_chunk<V, U>(ldc, j0, G, nvec, lc);
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-          const int j = j0 + k * G;
-          if (j < nvec) {
-            float o[V];
-#pragma unroll
-            for (int i = 0; i < V; ++i) {
-              const float v = (xv[k][i] - mu[k][i]) * sc[k][i] + sh[k][i];
-              if (rev) o[V - 1 - i] = v; else o[i] = v;
-              s += lc[k][i];
-            }
-            store_vec<T, V>(y + row * F + (int64_t)(rev ? nvec - 1 - j : j) * V, o);
-          }
-        }
-      }
-    }
-    s = group_sum(s, G);
-    if (row < B && sub == 0) ld_out[row] = from_f32<T>((ld_in ? to_f32(ld_in[row]) : 0.f) + to_f32(from_f32<T>(s)));
+  const float ldsum = to_f32(from_f32<T>(block_sum_vector(ldc, F)));
+  float mu[U][V], sc[U][V], sh[U][V];
+  if constexpr (HOIST) {
+    load_f32_chunk<V, U>(mean, sub, G, nvec, mu);
+    load_f32_chunk<V, U>(scale, sub, G, nvec, sc);
+    load_f32_chunk<V, U>(shift, sub, G, nvec, sh);
   }
-}
-
-// training: gx = scale*(gy - S1/B - x_hat*S2/B) - GLD*x_hat*rstd/B ;  eval: gx = scale*gy
-template <typename T, int V, int U>
-__global__ __launch_bounds__(kBlock) void bn_apply_bwd_kernel(
-    const T* __restrict__ x, const T* __restrict__ gy, const float* __restrict__ mean, const float* __restrict__ rstd,
-    const float* __restrict__ scale, const float* __restrict__ s1, const float* __restrict__ s2,
-    const float* __restrict__ gld_sum, T* __restrict__ gx, int64_t B, int F, float inv_b, int training, int rev, int G,
-    int64_t tiles) {
-  const int rpb = kBlock / G;
-  const int sub = threadIdx.x % G;
-  const int rloc = threadIdx.x / G;
-  const int nvec = F / V;
-  const float gls = training ? gld_sum[0] * inv_b : 0.f;
   for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
     const int64_t row = t * rpb + rloc;
     if (row >= B) continue;
     for (int j0 = sub; j0 < nvec; j0 += G * U) {
-      float xv[U][V], gv[U][V], mu[U][V], rs[U][V], sc[U][V], c1[U][V], c2[U][V];
-      if (training) {
-        load_chunk<T, V, U>(x + row * F, j0, G, nvec, xv);
+      float xv[U][V];
+      load_chunk<T, V, U>(x + row * F, j0, G, nvec, xv);
+      if constexpr (!HOIST) {
         load_f32_chunk<V, U>(mean, j0, G, nvec, mu);
-        load_f32_chunk<V, U>(rstd, j0, G, nvec, rs);
-        load_f32_chunk<V, U>(s1, j0, G, nvec, c1);
-        load_f32_chunk<V, U>(s2, j0, G, nvec, c2);
-      }
-      load_f32_chunk<V, U>(scale, j0, G, nvec, sc);
-#pragma unroll
-      for (int k = 0; k < U; ++k) {
-        int jj = j0 + k * G;
-        jj = jj < nvec ? jj : nvec - 1;
-        load_vec_rev<T, V>(gy + row * F, jj, nvec, rev != 0, gv[k]);
+        load_f32_chunk<V, U>(scale, j0, G, nvec, sc);
+        load_f32_chunk<V, U>(shift, j0, G, nvec, sh);
       }
 #pragma unroll
       for (int k = 0; k < U; ++k) {
@@ -484,13 +476,60 @@ __global__ __launch_bounds__(kBlock) void bn_apply_bwd_kernel(
           float o[V];
 #pragma unroll
           for (int i = 0; i < V; ++i) {
-            if (training) {
-              const float xh = (xv[k][i] - mu[k][i]) * rs[k][i];
-              o[i] = sc[k][i] * (gv[k][i] - c1[k][i] * inv_b - xh * c2[k][i] * inv_b) - gls * xh * rs[k][i];
-            } else {
-              o[i] = sc[k][i] * gv[k][i];
-            }
+            const float v = (xv[k][i] - mu[k][i]) * sc[k][i] + sh[k][i];
+            if (rev) o[V - 1 - i] = v; else o[i] = v;
           }
+          store_vec<T, V>(y + row * F + (int64_t)(rev ? nvec - 1 - j : j) * V, o);
+        }
+      }
+    }
+    if (sub == 0) ld_out[row] = from_f32<T>((ld_in ? to_f32(ld_in[row]) : 0.f) + ldsum);
+  }
+}
+
+// gx = scale*gy - k1 - (x - mean)*K   (training: k1, K from the finalize step; eval: k1 = K = 0)
+template <typename T, int V, int U, bool HOIST>
+__global__ __launch_bounds__(kBlock) void bn_apply_bwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ gy, const float* __restrict__ mean, const float* __restrict__ scale,
+    const float* __restrict__ k1, const float* __restrict__ kk, T* __restrict__ gx, int64_t B, int F, int training,
+    int rev, int G, int64_t tiles) {
+  const int rpb = kBlock / G;
+  const int sub = threadIdx.x % G;
+  const int rloc = threadIdx.x / G;
+  const int nvec = F / V;
+  float mu[U][V], sc[U][V], c1[U][V], c2[U][V];
+  if constexpr (HOIST) {
+    load_f32_chunk<V, U>(mean, sub, G, nvec, mu);
+    load_f32_chunk<V, U>(scale, sub, G, nvec, sc);
+    load_f32_chunk<V, U>(k1, sub, G, nvec, c1);
+    load_f32_chunk<V, U>(kk, sub, G, nvec, c2);
+  }
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t row = t * rpb + rloc;
+    if (row >= B) continue;
+    for (int j0 = sub; j0 < nvec; j0 += G * U) {
+      float xv[U][V], gv[U][V];
+      if (training) load_chunk<T, V, U>(x + row * F, j0, G, nvec, xv);
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        int jj = j0 + k * G;
+        jj = jj < nvec ? jj : nvec - 1;
+        load_vec_rev<T, V>(gy + row * F, jj, nvec, rev != 0, gv[k]);
+      }
+      if constexpr (!HOIST) {
+        load_f32_chunk<V, U>(mean, j0, G, nvec, mu);
+        load_f32_chunk<V, U>(scale, j0, G, nvec, sc);
+        load_f32_chunk<V, U>(k1, j0, G, nvec, c1);
+        load_f32_chunk<V, U>(kk, j0, G, nvec, c2);
+      }
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int j = j0 + k * G;
+        if (j < nvec) {
+          float o[V];
+#pragma unroll
+          for (int i = 0; i < V; ++i)
+            o[i] = training ? sc[k][i] * gv[k][i] - c1[k][i] - (xv[k][i] - mu[k][i]) * c2[k][i] : sc[k][i] * gv[k][i];
           store_vec<T, V>(gx + row * F + (int64_t)j * V, o);
         }
       }
@@ -498,19 +537,35 @@ __global__ __launch_bounds__(kBlock) void bn_apply_bwd_kernel(
   }
 }
 
-// geometry for the column-moment kernel: the row must fit kBnChunks vectors per lane
-static bool bn_geom(int64_t B, int64_t nvec, int* G_out, int64_t* tiles, int* grid) {
+// geometry for the column-moment kernel: >= 2 vectors per lane up to a whole wave per row, then wider groups
+// until the row fits kBnChunks vectors per lane
+static bool bn_geom(int64_t B, int64_t nvec, int* G_out, int* NJ_out, int64_t* tiles, int* grid) {
   int G = 1;
+  while (G < 64 && (int64_t)G * 2 < nvec) G <<= 1;
   while (G < kBlock && (int64_t)G * kBnChunks < nvec) G <<= 1;
   if ((int64_t)G * kBnChunks < nvec) return false;
-  if (G < 16 && nvec >= 16) G = 16;   // keep the partial stores reasonably coalesced
-  while (G > nvec && G > 1) G >>= 1;
-  if ((int64_t)G * kBnChunks < nvec) G <<= 1;
+  const int64_t per = (nvec + G - 1) / G;
+  *NJ_out = per >= 3 ? 4 : (per == 2 ? 2 : 1);
   const int rpb = kBlock / G;
   *G_out = G;
   *tiles = (B + rpb - 1) / rpb;
   *grid = (int)(*tiles < kBnGrid ? *tiles : kBnGrid);
   return true;
+}
+
+template <typename T, int V>
+static void bn_colstats_launch(int NJ, int grid, hipStream_t st, const T* x, const T* gy, const T* gld, const float* mean,
+                               const float* rstd, float* part, int64_t B, int F, int mode, int rev, int G,
+                               int64_t tiles) {
+  if (NJ == 1)
+    hipLaunchKernelGGL((bn_colstats_kernel<T, V, 1, 4>), dim3(grid), dim3(kBlock), 0, st, x, gy, gld, mean, rstd, part,
+                       B, F, mode, rev, G, tiles);
+  else if (NJ == 2)
+    hipLaunchKernelGGL((bn_colstats_kernel<T, V, 2, 4>), dim3(grid), dim3(kBlock), 0, st, x, gy, gld, mean, rstd, part,
+                       B, F, mode, rev, G, tiles);
+  else
+    hipLaunchKernelGGL((bn_colstats_kernel<T, V, 4, 2>), dim3(grid), dim3(kBlock), 0, st, x, gy, gld, mean, rstd, part,
+                       B, F, mode, rev, G, tiles);
 }
 
 template <typename T>
@@ -591,9 +646,11 @@ static int coupling_bwd_dispatch(const void* x, const void* s_raw, const float* 
 }
 
 // stats layout (floats, caller-owned, >= vae_bnflow_stats_floats(F)):
-//   [0,F) mean | [F,2F) var | [2F,3F) rstd | [3F,4F) scale | [4F,5F) shift | [5F,6F) ldc |
-//   [6F,7F) S1 | [7F,8F) S2 | [8F] sum gld | pad to 8F+4 | block partials kBnGrid * (2F+1)
-static size_t bn_stats_floats(int64_t F) { return 8 * (size_t)F + 4 + (size_t)kBnGrid * (2 * (size_t)F + 1); }
+//   [0,F) mean | [F,2F) var | [2F,3F) rstd | [3F,4F) scale | [4F,5F) beta | [5F,6F) ldc |
+//   [6F,7F) S1 | [7F,8F) S2 | [8F] sum gld | pad to 8F+4 | [8F+4, 9F+4) k1 | [9F+4, 10F+4) K |
+//   block partials kBnGrid * (2F+1)
+static size_t bn_stats_floats(int64_t F) { return 10 * (size_t)F + 4 + (size_t)kBnGrid * (2 * (size_t)F + 1); }
+constexpr int kBnApplyGrid = 2048;
 
 template <typename T>
 static int bn_fwd_dispatch(const void* x, const float* lg, const float* beta, const float* mean_in, const float* var_in,
@@ -601,38 +658,36 @@ static int bn_fwd_dispatch(const void* x, const float* lg, const float* beta, co
                            int training, int rev, hipStream_t st) {
   constexpr int VN = VecOf<T>::n;
   const bool vec = (F % VN == 0) && aligned16(x) && aligned16(y) && aligned16(stats);
-  float *mean = stats, *var = stats + F, *rstd = stats + 2 * F, *scale = stats + 3 * F, *shift = stats + 4 * F,
-        *ldc = stats + 5 * F, *part = stats + 8 * F + 4;
+  float *mean = stats, *scale = stats + 3 * F, *shift = stats + 4 * F, *ldc = stats + 5 * F,
+        *part = stats + 10 * F + 4;
   if (training) {
-    int G, grid;
+    int G, NJ, grid;
     int64_t tiles;
-    if (!bn_geom(B, vec ? F / VN : F, &G, &tiles, &grid)) return VAE_ERR_ARG;
+    if (!bn_geom(B, vec ? F / VN : F, &G, &NJ, &tiles, &grid)) return VAE_ERR_ARG;
     if (vec)
-      hipLaunchKernelGGL((bn_colstats_kernel<T, VN>), dim3(grid), dim3(kBlock), 0, st, (const T*)x, (const T*)nullptr,
-                         (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, part, B, (int)F, 0, 0, G, tiles);
+      bn_colstats_launch<T, VN>(NJ, grid, st, (const T*)x, nullptr, nullptr, nullptr, nullptr, part, B, (int)F, 0, 0, G,
+                                tiles);
     else
-      hipLaunchKernelGGL((bn_colstats_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, st, (const T*)x, (const T*)nullptr,
-                         (const T*)nullptr, (const float*)nullptr, (const float*)nullptr, part, B, (int)F, 0, 0, G, tiles);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((F + 31) / 32)), dim3(kBlock), 0, st, part, grid, x,
-                       (int)(sizeof(T) == 2), lg, beta, mean, var, scale, shift, ldc, rstd, (float*)nullptr, B, (int)F,
-                       eps, 0);
+      bn_colstats_launch<T, 1>(NJ, grid, st, (const T*)x, nullptr, nullptr, nullptr, nullptr, part, B, (int)F, 0, 0, G,
+                               tiles);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((F + kFinCols - 1) / kFinCols)), dim3(kBlock), 0, st, part,
+                       grid, x, (int)(sizeof(T) == 2), lg, beta, stats, B, (int)F, eps, 0, 1);
   } else {
-    if (hipMemcpyAsync(mean, mean_in, F * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(var, var_in, F * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
-      return VAE_ERR_LAUNCH;
     hipLaunchKernelGGL(bn_prepare_kernel, dim3((unsigned)((F + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, mean_in,
-                       var_in, lg, beta, scale, shift, ldc, rstd, (int)F);
+                       var_in, lg, beta, stats, (int)F);
   }
-  const RowGeom g = row_geom(B, vec ? F / VN : F, kGridStream);
+  const RowGeom g = row_geom(B, vec ? F / VN : F, kBnApplyGrid);
+  const bool hoist = (vec ? F / VN : F) <= (int64_t)g.G * g.U;
+#define VAE_BN_FWD(VV, HH)                                                                                            \
+  VAE_SWITCH_U(g.U, hipLaunchKernelGGL((bn_apply_fwd_kernel<T, VV, U, HH>), dim3(g.grid), dim3(kBlock), 0, st,        \
+                                       (const T*)x, mean, scale, shift, ldc, (T*)y, (const T*)ld_in, (T*)ld_out, B,   \
+                                       (int)F, rev, g.G, g.tiles))
   if (vec) {
-    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((bn_apply_fwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, st,
-                                         (const T*)x, mean, scale, shift, ldc, (T*)y, (const T*)ld_in, (T*)ld_out, B, (int)F,
-                                         rev, g.G, g.tiles));
+    if (hoist) { VAE_BN_FWD(VN, true); } else { VAE_BN_FWD(VN, false); }
   } else {
-    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((bn_apply_fwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, st,
-                                         (const T*)x, mean, scale, shift, ldc, (T*)y, (const T*)ld_in, (T*)ld_out, B, (int)F,
-                                         rev, g.G, g.tiles));
+    if (hoist) { VAE_BN_FWD(1, true); } else { VAE_BN_FWD(1, false); }
   }
+#undef VAE_BN_FWD
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 
@@ -641,31 +696,32 @@ static int bn_bwd_dispatch(const void* x, const void* gy, const void* gld, float
                            int training, int rev, hipStream_t st) {
   constexpr int VN = VecOf<T>::n;
   const bool vec = (F % VN == 0) && aligned16(x) && aligned16(gy) && aligned16(gx) && aligned16(stats);
-  float *mean = stats, *rstd = stats + 2 * F, *scale = stats + 3 * F, *s1 = stats + 6 * F, *s2 = stats + 7 * F,
-        *gsum = stats + 8 * F, *part = stats + 8 * F + 4;
-  int G, grid;
+  float *mean = stats, *rstd = stats + 2 * F, *scale = stats + 3 * F, *k1 = stats + 8 * F + 4, *kk = stats + 9 * F + 4,
+        *part = stats + 10 * F + 4;
+  int G, NJ, grid;
   int64_t tiles;
-  if (!bn_geom(B, vec ? F / VN : F, &G, &tiles, &grid)) return VAE_ERR_ARG;
+  if (!bn_geom(B, vec ? F / VN : F, &G, &NJ, &tiles, &grid)) return VAE_ERR_ARG;
   if (vec)
-    hipLaunchKernelGGL((bn_colstats_kernel<T, VN>), dim3(grid), dim3(kBlock), 0, st, (const T*)x, (const T*)gy,
-                       (const T*)gld, mean, rstd, part, B, (int)F, 1, rev, G, tiles);
+    bn_colstats_launch<T, VN>(NJ, grid, st, (const T*)x, (const T*)gy, (const T*)gld, mean, rstd, part, B, (int)F, 1,
+                              rev, G, tiles);
   else
-    hipLaunchKernelGGL((bn_colstats_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, st, (const T*)x, (const T*)gy,
-                       (const T*)gld, mean, rstd, part, B, (int)F, 1, rev, G, tiles);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((F + 31) / 32)), dim3(kBlock), 0, st, part, grid,
-                     (const void*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, s1, s2, (float*)nullptr,
-                     (float*)nullptr, (float*)nullptr, (float*)nullptr, gsum, B, (int)F, 0.f, 1);
-  const RowGeom g = row_geom(B, vec ? F / VN : F, kGridStream);
-  const float inv_b = 1.0f / (float)B;
+    bn_colstats_launch<T, 1>(NJ, grid, st, (const T*)x, (const T*)gy, (const T*)gld, mean, rstd, part, B, (int)F, 1, rev,
+                             G, tiles);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((F + kFinCols - 1) / kFinCols)), dim3(kBlock), 0, st, part, grid,
+                     (const void*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, stats, B, (int)F, 0.f, 1,
+                     training);
+  const RowGeom g = row_geom(B, vec ? F / VN : F, kBnApplyGrid);
+  const bool hoist = (vec ? F / VN : F) <= (int64_t)g.G * g.U;
+#define VAE_BN_BWD(VV, HH)                                                                                            \
+  VAE_SWITCH_U(g.U, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, VV, U, HH>), dim3(g.grid), dim3(kBlock), 0, st,        \
+                                       (const T*)x, (const T*)gy, mean, scale, k1, kk, (T*)gx, B, (int)F, training,   \
+                                       rev, g.G, g.tiles))
   if (vec) {
-    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, st,
-                                         (const T*)x, (const T*)gy, mean, rstd, scale, s1, s2, gsum, (T*)gx, B, (int)F,
-                                         inv_b, training, rev, g.G, g.tiles));
+    if (hoist) { VAE_BN_BWD(VN, true); } else { VAE_BN_BWD(VN, false); }
   } else {
-    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((bn_apply_bwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, st,
-                                         (const T*)x, (const T*)gy, mean, rstd, scale, s1, s2, gsum, (T*)gx, B, (int)F,
-                                         inv_b, training, rev, g.G, g.tiles));
+    if (hoist) { VAE_BN_BWD(1, true); } else { VAE_BN_BWD(1, false); }
   }
+#undef VAE_BN_BWD
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 
