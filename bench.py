@@ -157,6 +157,8 @@ def main():
         ['gauss_reparam_kl_fwd', 'nll_elbo_fwd', 'nll_elbo_bwd', 'gauss_reparam_kl_bwd']
     pmeans = ctypes_off(scalars, 6)
 
+    overlap = dist is not None and backend == 'nccl' and os.environ.get('BENCH_SYNC_ALLREDUCE', '0') != '1'
+    pending = [None]
     step_no = [1]   # Philox call offset: a fresh draw every step, the same one in that step's backward
 
     def step(ev=None):
@@ -175,7 +177,13 @@ def main():
                  ptr(elbo), ptr(scalars), ptr(ws), B, D, 0, st)
         mark(2)
         if dist is not None:
-            all_reduce(scalars)               # global-batch means (abstract_vae.py:381-387) in one message
+            # global-batch means (abstract_vae.py:381-387) in one 8-float message.  Nothing later in the step reads
+            # them (the kernels pre-scale by 1/B_global), so over RCCL the collective runs on its own stream beside
+            # the backward kernels and is joined at the end of the step.
+            if overlap:
+                pending[0] = dist.all_reduce(scalars, op=dist.ReduceOp.SUM, async_op=True)
+            else:
+                all_reduce(scalars)
         mark(3)
         if fused:
             call('vae_nll_fused_grad_finish', ptr(grecon), ptr(gmeans), B * D, 0, st)
@@ -187,6 +195,9 @@ def main():
         call('vae_gauss_reparam_kl_bwd', ptr(logits), 2 * L, noise_arg[0], ptr(gz), L, None, ptr(gkld), None,
              ptr(glogits), 2 * L, B, L, 1e-6, mean_scale, 1, 1234, step_no[0], row0, 0, st)
         mark(5)
+        if pending[0] is not None:
+            pending[0].wait()                 # the launch stream waits for the collective; no host block
+            pending[0] = None
         step_no[0] += 1
 
     for _ in range(args.warmup):
