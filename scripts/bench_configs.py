@@ -228,6 +228,38 @@ def flowtail(B, F):
     timeit('coupling_tail_bwd', cfg, lambda: call('vae_coupling_tail_bwd', ptr(x), ptr(s_raw), ptr(mask), ptr(gu), ptr(gld), ptr(gx), ptr(gs), ptr(gt), B, F, 0, st), B * (24 * F + 4))
 
 
+def graph_step(B, L):
+    """The whole module-level ELBO step (IsotropicGaussian + Bernoulli loss_function + autograd backward): eager
+    launches from Python vs one HIP graph replay (launch-bound at the small configs)."""
+    from vae_amd.reparameterizers import IsotropicGaussian
+    from vae_amd.elbo import loss_function
+    m = IsotropicGaussian({'continuous_size': 2 * L, 'cuda': True, 'half': False})
+    m.train()
+    lg = T(B, 2 * L).requires_grad_(True)
+    rc = T(B, 1, 28, 28).requires_grad_(True)
+    xi = (T(B, 1, 28, 28, kind='rand') < 0.13).float()
+    gz = T(B, L)
+
+    def step():
+        z, params = m(lg)
+        out = loss_function(rc, xi, m.kl(params), 'bernoulli')
+        return torch.autograd.grad([out['loss_mean'], z], [lg, rc], [None, gz], allow_unused=True)
+
+    nbytes = B * ((12 * L + 4) + (20 * L + 4) + (12 * 784 + 12))
+    cfg = 'B=%d L=%d 1x28x28 f32 module fwd+loss+bwd' % (B, L)
+    timeit('elbo step (eager)', cfg, step, nbytes)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    timeit('elbo step (HIP graph)', cfg, graph.replay, nbytes)
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--json', default=None)
@@ -241,6 +273,10 @@ if __name__ == '__main__':
         nll(B, 784, 0, 'bernoulli')
     nll(65536, 784, 0, 'bernoulli', dtype=torch.bfloat16)
     nll_fused(65536, 784, 0, 'bernoulli')
+    print('== C1-sized steps: eager launches vs one HIP graph')
+    graph_step(4096, 32)
+    graph_step(16384, 128)
+    graph_step(65536, 512)
     print('== C3: Gumbel-softmax / Concat')
     for K in (32, 256, 1024):
         gumbel(65536, K)

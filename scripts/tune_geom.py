@@ -22,15 +22,21 @@ ks = {
     'gauss_fwd_philox': (lambda: call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, None, ptr(z), 0, ptr(logvar), ptr(kl), ptr(scal), ptr(ws), B, L, 1e-6, 1.0 / (B * L), 1, 1, 1, 0, 0, st), (12 * L + 4) * B),
     'gauss_bwd': (lambda: call('vae_gauss_reparam_kl_bwd', ptr(logits), 2 * L, ptr(noise), ptr(gz), 0, None, ptr(gkld), None, ptr(glogits), 0, B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st), (24 * L + 4) * B),
     'nll_fwd': (lambda: call('vae_nll_elbo_fwd', ptr(x), ptr(recon), 0, ptr(kl), None, None, 1.0, 1.0 / B, ptr(nll), ptr(loss), ptr(elbo), ptr(scal), ptr(ws), B, D, 0, st), (8 * D + 12) * B),
+    'nll_fused': (lambda: call('vae_nll_elbo_fused', ptr(x), ptr(recon), 0, ptr(kl), None, None, 1.0, 1.0 / B, 1.0, ptr(nll), ptr(loss), ptr(elbo), ptr(scal), ptr(ws), ptr(grecon), B, D, 0, st), (12 * D + 12) * B),
     'nll_bwd': (lambda: call('vae_nll_elbo_bwd', ptr(x), ptr(recon), 0, None, None, None, ptr(gmeans), 1.0, 1.0 / B, ptr(grecon), ptr(gkld), None, None, B, D, 0, st), 12 * D * B),
 }
+only = os.environ.get('TUNE_ONLY')
 for name, (fn, nbytes) in ks.items():
-    for G in (sys.argv[1:] or ['']):
-        G = '' if G == 'auto' else G
-        if G:
-            os.environ['VAE_AMD_G'] = G
-        else:
-            os.environ.pop('VAE_AMD_G', None)
+    if only and name not in only.split(','):
+        continue
+    for spec in (sys.argv[1:] or ['']):   # 'auto' | 'G' | 'GxU'
+        G, _, Uo = ('' if spec == 'auto' else spec).partition('x')
+        for key, val in (('VAE_AMD_G', G), ('VAE_AMD_U', Uo)):
+            if val:
+                os.environ[key] = val
+            else:
+                os.environ.pop(key, None)
+        G = spec
         for _ in range(5):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

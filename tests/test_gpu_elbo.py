@@ -256,3 +256,35 @@ def test_fused_backward_bf16_and_no_grad():
     with torch.no_grad():    # no graph: the plain forward kernel, no gradient buffer
         r = E.loss_function(rd, x.to(DEV).bfloat16(), None, 'bernoulli')
     assert not r['loss_mean'].requires_grad
+
+
+def test_autoencoder_and_nokl_losses():
+    """autoencoder.py:12-32, :92-115: NLL-only objectives (dict schema of the reference, values vs the oracle)."""
+    from vae_amd.elbo import AutoencoderMixin, VAENoKLMixin
+    torch.manual_seed(6)
+    x, recon = images(33, 1, 28, 28, 'bernoulli')
+    n0 = O.nll(x, recon, 'bernoulli')
+
+    class AE(AutoencoderMixin):
+        config = {'nll_type': 'bernoulli', 'half': False}
+        training = True
+
+    class NoKL(VAENoKLMixin):
+        config = {'nll_type': 'bernoulli', 'half': False}
+        training = True
+
+    rd = recon.to(DEV).requires_grad_(True)
+    out = AE().loss_function(rd, x.to(DEV))
+    assert set(out) == {'loss', 'elbo', 'loss_mean', 'elbo_mean', 'nll_mean', 'kld_mean', 'kl_beta_scalar',
+                        'proxy_mean', 'mut_info_mean'}
+    close(out['loss'], n0, rtol=1e-5, atol=1e-3)
+    close(out['loss_mean'], n0.mean(), rtol=1e-5, atol=1e-4)
+    assert AE().reparameterize(rd)[0] is rd and float(out['elbo'].abs().max()) == 0.0
+    (g,) = torch.autograd.grad(out['loss_mean'], rd)
+    rc = recon.clone().requires_grad_(True)
+    (g0,) = torch.autograd.grad(O.nll(x, rc, 'bernoulli').mean(), rc)
+    close(g, g0, rtol=1e-5, atol=2e-7 * float(g0.abs().max()))
+    out = NoKL().loss_function(rd, x.to(DEV), {})
+    assert set(out) == {'loss', 'loss_mean', 'elbo_mean', 'nll_mean', 'kld_mean', 'proxy_mean', 'mut_info_mean'}
+    close(out['nll_mean'], n0.mean(), rtol=1e-5, atol=1e-4)
+    assert float(out['kld_mean']) == 0.0

@@ -8,6 +8,6 @@ sharding + the packed scalar all-reduce).
 from . import _lib  # noqa: F401
 from . import functional  # noqa: F401
 from .reparameterizers import get_reparameterizer, is_module_a_reparameterizer, reparam_dict  # noqa: F401
-from .elbo import ELBOMixin, loss_function, nll, vrnn_loss_function  # noqa: F401
+from .elbo import ELBOMixin, MSGMixin, AutoencoderMixin, VAENoKLMixin, loss_function, nll, vrnn_loss_function  # noqa: F401
 
 EPS_TOL = 1e-6

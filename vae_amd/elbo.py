@@ -172,3 +172,30 @@ class MSGMixin(ELBOMixin):
 
     def reparameterize(self, logits, force=False):
         return reparameterize_multi(self.reparameterizer, logits, self.config['max_time_steps'], force=force)
+
+
+class AutoencoderMixin(ELBOMixin):
+    """Autoencoder's latent/loss half (autoencoder.py:37-46, :92-115): no reparameterization, the loss is the
+    NLL alone -- one launch for nll, its mean and (in training) d(loss_mean)/d(recon_x)."""
+
+    def reparameterize(self, logits, labels=None, force=False):
+        return logits, {}
+
+    def loss_function(self, recon_x, x, **unused_kwargs):
+        nll_, _, _, means = F_.nll_elbo(x, recon_x, self.config['nll_type'], inv_count=self.inv_count,
+                                        fuse_backward=True)
+        m = means.to(nll_.dtype)
+        return {'loss': nll_, 'elbo': torch.zeros_like(nll_), 'loss_mean': m[2], 'elbo_mean': 0, 'nll_mean': m[2],
+                'kld_mean': 0, 'kl_beta_scalar': 0, 'proxy_mean': 0, 'mut_info_mean': 0}
+
+
+class VAENoKLMixin(ELBOMixin):
+    """VAENoKL.loss_function (autoencoder.py:12-32): reparameterizes as usual, the objective drops the KL."""
+
+    def loss_function(self, recon_x, x, reparam_map):
+        nll_, _, _, means = F_.nll_elbo(x, recon_x, self.config['nll_type'], inv_count=self.inv_count,
+                                        fuse_backward=True)
+        m = means.to(nll_.dtype)
+        zero = m[3] * 0     # mean of zeros_like(nll): a device scalar, as in the reference
+        return {'loss': nll_, 'loss_mean': m[2], 'elbo_mean': zero, 'nll_mean': m[2], 'kld_mean': zero,
+                'proxy_mean': zero, 'mut_info_mean': zero}

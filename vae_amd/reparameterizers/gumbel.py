@@ -57,6 +57,8 @@ class GumbelSoftmax(nn.Module):
 
     def reparmeterize(self, logits, noise=None):
         assert self.dim in (-1, logits.dim() - 1), "the HIP path reduces over the last dim"
+        if noise is None:
+            noise = rng.captured_noise('uniform', logits.shape, logits)   # None unless a HIP graph is capturing
         seed, offset = (0, 0) if noise is not None else rng.next_call()
         return F_.gumbel_softmax(logits, unif=noise, tau=float(self.tau), seed=seed, offset=offset,
                                  row0=self.row_offset)
@@ -65,6 +67,15 @@ class GumbelSoftmax(nn.Module):
         # gumbel.py:153-157: sum p_z log q(z|xhat) - sum p_z log q(z|x) with p_z = softmax(logits) = exp(log_q_z),
         # i.e. -KL(q(z|x) || q(z|xhat)): one launch of the categorical-KL kernel instead of six torch ops.
         return -F_.categorical_kl(params['discrete']['log_q_z'], params['q_z_given_xhat']['discrete']['log_q_z'])
+
+    def mutual_info_analytic(self, params, eps=1e-9):
+        # gumbel.py:126-141 (not the live form: mutual_info() returns the Monte-Carlo one): plain PyTorch
+        targets = torch.argmax(F.softmax(params['discrete']['logits'], -1), dim=-1).long()
+        crossent_loss = F.cross_entropy(input=params['q_z_given_xhat']['discrete']['logits'], target=targets,
+                                        reduction='none')
+        ent_loss = -torch.sum(D.OneHotCategorical(logits=params['discrete']['z_hard'],
+                                                  validate_args=False).entropy(), -1)
+        return ent_loss + crossent_loss
 
     def mutual_info(self, params, eps=1e-9):
         return self.config['discrete_mut_info'] * self.mutual_info_monte_carlo(params)

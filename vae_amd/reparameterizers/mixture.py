@@ -37,6 +37,10 @@ class Mixture(nn.Module):
         disc_params = self.discrete.prior_params(batch_size, **kwargs)
         return {**disc_params, **cont_params}
 
+    def prior_distribution(self, batch_size, **kwargs):
+        return {'continuous': self.continuous.prior_distribution(batch_size, **kwargs),
+                'discrete': self.discrete.prior_distribution(batch_size, **kwargs)}
+
     def prior(self, batch_size, **kwargs):
         disc = self.discrete.prior(batch_size, **kwargs)
         cont = self.continuous.prior(batch_size, **kwargs)
@@ -65,6 +69,10 @@ class Mixture(nn.Module):
         key = 'gaussian' if not self.is_beta else 'beta'
         params = {'logits': logits, 'z': merged, key: continuous_params[key], 'discrete': disc_params['discrete']}
         return merged, params
+
+    def reparmeterize(self, logits, force=False, noise=None):
+        # mixture.py:91-107 (the reference class defines no forward(); nn.Module callers go through this)
+        return self.forward(logits, force=force, noise=noise)
 
     def kl(self, dist_a, prior=None):
         return self.continuous.kl(dist_a, prior) + self.discrete.kl(dist_a, prior)

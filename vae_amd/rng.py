@@ -35,3 +35,20 @@ def manual_seed(seed):
     torch.manual_seed(seed)
     _state['seed'] = torch.initial_seed()
     _state['offset'] = 0
+
+
+def capturing():
+    """True while torch's current HIP stream is being captured into a graph."""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def captured_noise(kind, shape, like):
+    """Noise for a draw issued during HIP graph capture, else None.  The (seed, offset) pair of an in-kernel
+    Philox draw is a host value: captured, it would be frozen into the graph and every replay would repeat the
+    same draw.  torch's generator is graph-aware (its Philox offset lives on the device and advances on replay),
+    so while capturing the draw is made by torch and handed to the kernel as injected noise."""
+    if not capturing():
+        return None
+    if kind == 'normal':
+        return torch.randn(shape, dtype=like.dtype, device=like.device)
+    return torch.rand(shape, dtype=like.dtype, device=like.device)
