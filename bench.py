@@ -83,6 +83,9 @@ def main():
     ap.add_argument('--batch', type=int, default=B_PER_GPU, help='samples per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--two-pass', action='store_true', help='separate NLL forward and backward kernels')
+    ap.add_argument('--materialize-logvar', action='store_true',
+                    help="also write params['gaussian']['logvar'] in the forward (the module classes produce it on first "
+                         "read instead: nothing in the training step reads it)")
     ap.add_argument('--noise', choices=['injected', 'philox'], default='injected',
                     help='injected: eps read from HBM (the parity-test form); philox: drawn inside the kernels')
     args = ap.parse_args()
@@ -152,6 +155,7 @@ def main():
 
     fused = not args.two_pass
     philox = args.noise == 'philox'
+    plogvar = ptr(logvar) if args.materialize_logvar else None
     noise_arg = [None if philox else ptr(noise)]   # None: the kernels draw Philox noise themselves
     names = ['gauss_reparam_kl_fwd', 'nll_elbo_fused', 'grad_finish', 'gauss_reparam_kl_bwd'] if fused else \
         ['gauss_reparam_kl_fwd', 'nll_elbo_fwd', 'nll_elbo_bwd', 'gauss_reparam_kl_bwd']
@@ -166,7 +170,7 @@ def main():
             if ev is not None:
                 ev[i].record()
         mark(0)
-        call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, noise_arg[0], ptr(z), L, ptr(logvar), ptr(kl), pmeans,
+        call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, noise_arg[0], ptr(z), L, plogvar, ptr(kl), pmeans,
              ptr(ws), B, L, 1e-6, mean_scale, 1, 1234, step_no[0], row0, 0, st)
         mark(1)
         if fused:
@@ -318,7 +322,8 @@ def main():
                                    'Bernoulli NLL; step = reparam+KL fwd, NLL+ELBO fwd, both backward (%s)'
                                    % (B, 'NLL forward and gradient in one pass' if fused else 'two-pass NLL'),
                        'global_batch': B * world, 'latent': L, 'pixels': D, 'parallelism': 'dp%d' % world,
-                       'noise': 'in-kernel Philox4x32-10' if philox else 'injected (resident in HBM)'},
+                       'noise': 'in-kernel Philox4x32-10' if philox else 'injected (resident in HBM)',
+                       'logvar_output': 'materialized' if args.materialize_logvar else 'on first read (not written)'},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': kernels[dom]['achieved_GBs'],
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kernels[dom]['frac'], 'traffic': traffic},
             'kernels': kernels,

@@ -165,3 +165,34 @@ def test_empty_batch():
     m = mod(4)
     z, p = m(torch.zeros(0, 8, device=DEV), noise=torch.zeros(0, 4, device=DEV))
     assert z.shape == (0, 4) and m.kl(p).shape == (0,)
+
+
+def test_logvar_is_produced_on_first_read():
+    """params['gaussian']['logvar'] (isotropic_gaussian.py:124-125) is not written by the forward launch; the first
+    read runs the reference's own op and yields the same bits, with gradient to the logits; kl() never needs it."""
+    from vae_amd.lazy import LazyParams
+    torch.manual_seed(4)
+    B, L = 64, 24
+    logits, noise = torch.randn(B, 2 * L), torch.randn(B, L)
+    m = mod(L)
+    lg = logits.to(DEV).requires_grad_(True)
+    z, params = m(lg, noise=noise.to(DEV))
+    g = params['gaussian']
+    assert isinstance(g, LazyParams) and g.is_pending('logvar')
+    assert list(g) == ['z', 'mu', 'logvar', 'mu_mean', 'logvar_mean']       # the reference's key order
+    kl = m.kl(params)
+    assert g.is_pending('logvar')                                            # the fused KL did not need it
+    z0, p0 = O.gauss_forward(logits, noise)
+    close(kl, O.gauss_kl(p0), atol=1e-4)
+    lv = g['logvar']
+    assert not g.is_pending('logvar') and g['logvar'] is lv
+    assert torch.equal(lv.detach().cpu(), p0['gaussian']['logvar'])
+    (gl,) = torch.autograd.grad(lv.sum(), lg)
+    assert torch.equal(gl[:, :L].cpu(), torch.zeros(B, L)) and torch.equal(gl[:, L:].cpu(), torch.ones(B, L))
+    # a plain copy of the params (what ConcatReparameterizer's {**child_params} does) reads it too
+    z2, params2 = m(lg, noise=noise.to(DEV))
+    flat = {**params2['gaussian']}
+    assert type(flat) is dict and torch.equal(flat['logvar'].detach().cpu(), p0['gaussian']['logvar'])
+    # the prior form of kl() reads both logvars
+    klp = m.kl(params2, params)
+    close(klp, torch.zeros(B), atol=1e-5)

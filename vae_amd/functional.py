@@ -46,12 +46,12 @@ class _Guard(object):
 # --------------------------------------------------------------------------------------
 class _GaussReparamKL(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, noise, eps_tol, training, seed, offset, row0, mean_scale):
+    def forward(ctx, logits, noise, eps_tol, training, seed, offset, row0, mean_scale, want_logvar=True):
         ctx.set_materialize_grads(False)
         dev = check_device(logits, noise)
         B, L = logits.shape[0], logits.shape[1] // 2
         z = torch.empty((B, L), dtype=logits.dtype, device=dev) if training else None
-        logvar = torch.empty((B, L), dtype=logits.dtype, device=dev)
+        logvar = torch.empty((B, L), dtype=logits.dtype, device=dev) if want_logvar else None
         kl = torch.empty((B,), dtype=logits.dtype, device=dev)
         means = torch.zeros((2,), dtype=torch.float32, device=dev)
         if mean_scale is None:
@@ -62,15 +62,23 @@ class _GaussReparamKL(torch.autograd.Function):
                  offset & _MASK64, row0, dtype_code(logits), stream_ptr(dev))
         ctx.save_for_backward(logits, noise)
         ctx.cfg = (eps_tol, training, seed, offset, row0, mean_scale)
+        nd = []
         if z is None:
             z = logits.new_empty((0,))
-            ctx.mark_non_differentiable(z)
+            nd.append(z)
+        if logvar is None:
+            logvar = logits.new_empty((0,))
+            nd.append(logvar)
+        if nd:
+            ctx.mark_non_differentiable(*nd)
         return z, logvar, kl, means
 
     @staticmethod
     def backward(ctx, gz, glogvar, gkl, gmeans):
         logits, noise = ctx.saved_tensors
         eps_tol, training, seed, offset, row0, mean_scale = ctx.cfg
+        if glogvar is not None and glogvar.numel() == 0:
+            glogvar = None
         dev = logits.device
         B, L = logits.shape[0], logits.shape[1] // 2
         if not training:
@@ -82,11 +90,13 @@ class _GaussReparamKL(torch.autograd.Function):
             call('vae_gauss_reparam_kl_bwd', ptr(logits), logits.stride(0), ptr(noise), ptr(gz), 0, ptr(glogvar),
                  ptr(gkl), ptr(gmeans), ptr(glogits), 0, B, L, eps_tol, mean_scale, int(training), seed & _MASK64,
                  offset & _MASK64, row0, dtype_code(logits), stream_ptr(dev))
-        return glogits, None, None, None, None, None, None, None
+        return glogits, None, None, None, None, None, None, None, None
 
 
-def gauss_reparam_kl(logits, noise=None, eps_tol=1e-6, training=True, seed=0, offset=0, row0=0, mean_scale=None):
-    """logits [B, 2L] -> (z [B, L] or None in eval, logvar [B, L], kl [B], means float32[2]).
+def gauss_reparam_kl(logits, noise=None, eps_tol=1e-6, training=True, seed=0, offset=0, row0=0, mean_scale=None,
+                     want_logvar=True):
+    """logits [B, 2L] -> (z [B, L] or None in eval, logvar [B, L] (None unless `want_logvar`), kl [B],
+    means float32[2]).
 
     Reference: reparameterizers/isotropic_gaussian.py:77-131, :158-170, :204-215.
     `noise` None in training draws Philox N(0,1) in the kernel keyed by (seed, offset, row0+row).
@@ -95,8 +105,8 @@ def gauss_reparam_kl(logits, noise=None, eps_tol=1e-6, training=True, seed=0, of
     if noise is not None:
         noise = noise.reshape(logits.shape[0], logits.shape[1] // 2).contiguous()
     z, logvar, kl, means = _GaussReparamKL.apply(logits, noise, float(eps_tol), bool(training), int(seed),
-                                                 int(offset), int(row0), mean_scale)
-    return (z if training else None), logvar, kl, means
+                                                 int(offset), int(row0), mean_scale, bool(want_logvar))
+    return (z if training else None), (logvar if want_logvar else None), kl, means
 
 
 class _GaussKL(torch.autograd.Function):
@@ -731,11 +741,11 @@ class _ConcatLeaves(torch.autograd.Function):
                 kind, n = spec[0], spec[1]
                 if kind == 'gauss':
                     _, L, eps_tol, mean_scale = spec
-                    logvar, kl = new(B, L), new(B)
+                    logvar, kl = logits.new_empty((0,)), new(B)   # logvar is produced lazily by the module class
                     means = torch.zeros((2,), dtype=torch.float32, device=dev)
                     ms = 1.0 / max(B * L, 1) if mean_scale is None else mean_scale
                     call('vae_gauss_reparam_kl_fwd', _poff(logits, i_off), rs, ptr(noise), _poff(zcat, o_off), W_out,
-                         ptr(logvar), ptr(kl), ptr(means), ptr(workspace(dev)), B, L, eps_tol, ms, int(training),
+                         None, ptr(kl), ptr(means), ptr(workspace(dev)), B, L, eps_tol, ms, int(training),
                          seed & _MASK64, offset & _MASK64, row0, dt, st)
                     outs += [logvar, kl, means]
                     i_off, o_off = i_off + 2 * L, o_off + L
@@ -781,7 +791,7 @@ class _ConcatLeaves(torch.autograd.Function):
                 kind = spec[0]
                 if kind == 'gauss':
                     _, L, eps_tol, mean_scale = spec
-                    glv, gkl, gm = _dense(gex[k]), _dense(gex[k + 1]), gex[k + 2]
+                    glv, gkl, gm = None, _dense(gex[k + 1]), gex[k + 2]
                     gm = None if gm is None else gm.contiguous().float()
                     ms = 1.0 / max(B * L, 1) if mean_scale is None else mean_scale
                     gz_p, gz_s = gslice(o_off)
@@ -813,7 +823,7 @@ class _ConcatLeaves(torch.autograd.Function):
 
 def concat_leaves(logits, specs, training, noises, seeds, row0=0):
     """Run kernel-backed Concat children over one [B, sum(in)] logits buffer.  Returns the flat tuple
-    (zcat, then per child: gauss -> logvar, kl, means[2]; gumbel -> other, log_q_z; bern -> other), where
+    (zcat, then per child: gauss -> (empty placeholder), kl, means[2]; gumbel -> other, log_q_z; bern -> other), where
     `other` is z_hard in training (y went into zcat) and y in eval (z_hard went into zcat)."""
     logits = _rows(logits)
     B = logits.shape[0]
@@ -831,12 +841,12 @@ def concat_leaves(logits, specs, training, noises, seeds, row0=0):
 # --------------------------------------------------------------------------------------
 class _GaussMulti(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, noise, S, eps_tol, seed, offset, row0, mean_scale):
+    def forward(ctx, logits, noise, S, eps_tol, seed, offset, row0, mean_scale, want_logvar=True):
         ctx.set_materialize_grads(False)
         dev = check_device(logits, noise)
         B, L = logits.shape[0], logits.shape[1] // 2
         z = torch.empty((S, B, L), dtype=logits.dtype, device=dev)
-        logvar = torch.empty((B, L), dtype=logits.dtype, device=dev)
+        logvar = torch.empty((B, L), dtype=logits.dtype, device=dev) if want_logvar else None
         kl = torch.empty((B,), dtype=logits.dtype, device=dev)
         means = torch.zeros((2,), dtype=torch.float32, device=dev)
         if mean_scale is None:
@@ -847,6 +857,9 @@ class _GaussMulti(torch.autograd.Function):
                  dtype_code(logits), stream_ptr(dev))
         ctx.save_for_backward(logits, noise)
         ctx.cfg = (S, eps_tol, seed, offset, row0, mean_scale)
+        if logvar is None:
+            logvar = logits.new_empty((0,))
+            ctx.mark_non_differentiable(logvar)
         return z, logvar, kl, means
 
     @staticmethod
@@ -855,6 +868,8 @@ class _GaussMulti(torch.autograd.Function):
         S, eps_tol, seed, offset, row0, mean_scale = ctx.cfg
         dev = logits.device
         B, L = logits.shape[0], logits.shape[1] // 2
+        if glogvar is not None and glogvar.numel() == 0:
+            glogvar = None
         gz, glogvar, gkl = _dense(gz), _dense(glogvar), _dense(gkl)
         gmeans = None if gmeans is None else gmeans.contiguous().float()
         glogits = torch.empty((B, 2 * L), dtype=logits.dtype, device=dev)
@@ -862,10 +877,11 @@ class _GaussMulti(torch.autograd.Function):
             call('vae_gauss_reparam_multi_bwd', ptr(logits), logits.stride(0), ptr(noise), ptr(gz), ptr(glogvar),
                  ptr(gkl), ptr(gmeans), ptr(glogits), B, L, S, eps_tol, mean_scale, seed & _MASK64, offset & _MASK64,
                  row0, dtype_code(logits), stream_ptr(dev))
-        return glogits, None, None, None, None, None, None, None
+        return glogits, None, None, None, None, None, None, None, None
 
 
-def gauss_reparam_multi(logits, num_samples, noise=None, eps_tol=1e-6, seed=0, offset=0, row0=0, mean_scale=None):
+def gauss_reparam_multi(logits, num_samples, noise=None, eps_tol=1e-6, seed=0, offset=0, row0=0, mean_scale=None,
+                        want_logvar=True):
     """logits [B, 2L] -> (z [S, B, L], logvar [B, L], kl [B], means float32[2]): S training-mode draws
     from one read of the logits.  `noise` [S, B, L] (or a list of S [B, L] tensors) injects the draws;
     None: Philox, draw s on call offset `offset + s`."""
@@ -876,7 +892,9 @@ def gauss_reparam_multi(logits, num_samples, noise=None, eps_tol=1e-6, seed=0, o
         if isinstance(noise, (list, tuple)):
             noise = torch.stack([n.reshape(B, L) for n in noise], 0)
         noise = noise.reshape(S, B, L).to(logits.dtype).contiguous()
-    return _GaussMulti.apply(logits, noise, S, float(eps_tol), int(seed), int(offset), int(row0), mean_scale)
+    z, logvar, kl, means = _GaussMulti.apply(logits, noise, S, float(eps_tol), int(seed), int(offset), int(row0),
+                                             mean_scale, bool(want_logvar))
+    return z, (logvar if want_logvar else None), kl, means
 
 
 class _NllMultiElbo(torch.autograd.Function):

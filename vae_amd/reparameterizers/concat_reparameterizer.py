@@ -7,6 +7,7 @@ import torch.nn as nn
 
 from .. import functional as F_
 from .. import rng
+from ..lazy import LazyParams
 from .bernoulli import Bernoulli
 from .gumbel import GumbelSoftmax
 from .isotropic_gaussian import EPS_TOL, IsotropicGaussian
@@ -76,9 +77,11 @@ class ConcatReparameterizer(nn.Module):
             if kind == 'gauss':
                 logits_i = logits[:, i_off:i_off + 2 * n_out]
                 mu = logits_i[:, :n_out]
-                logvar, kl, means = outs[k], outs[k + 1], outs[k + 2].to(logits.dtype)
-                logvar._vae_amd_kl = (kl, mu)
-                g = {'z': z_i, 'mu': mu, 'logvar': logvar, 'mu_mean': means[0], 'logvar_mean': means[1]}
+                kl, means = outs[k + 1], outs[k + 2].to(logits.dtype)
+                g = LazyParams({'z': z_i, 'mu': mu})
+                g.set_lazy('logvar', lambda li=logits_i, n=n_out: li[:, n:] + EPS_TOL)   # on first read only
+                g._vae_amd_kl = (kl, mu)
+                g['mu_mean'], g['logvar_mean'] = means[0], means[1]
                 params = {'z': z_i, 'logits': logits_i, 'gaussian': g}
                 k, i_off = k + 3, i_off + 2 * n_out
             else:

@@ -3,8 +3,10 @@ routed through the fused HIP kernels.
 
 forward(): one launch does the mu/logvar split, `+ eps`, `z = e*(0.5*logvar) + mu` (NO exp,
 reference :87-92), KL vs N(0,1) (:158-170) and the two means (:213-214).  The KL is kept on
-the returned `logvar` tensor so that kl(params) costs nothing; kl() on foreign params or with a
-prior runs the standalone KL kernel.  No CPU path: CPU tensors raise.
+the returned params dict so that kl(params) costs nothing; kl() on foreign params or with a
+prior runs the standalone KL kernel.  params['gaussian']['logvar'] is produced on first read
+(vae_amd/lazy.py): the training step never reads it, so its 4L bytes per sample are not written.
+No CPU path: CPU tensors raise.
 """
 import numpy as np
 import torch
@@ -13,6 +15,7 @@ import torch.distributions as D
 
 from .. import functional as F_
 from .. import rng
+from ..lazy import LazyParams
 
 EPS_TOL = 1e-6  # helpers.utils.eps(half=False): assumed, helpers is un-vendored
 
@@ -75,20 +78,23 @@ class IsotropicGaussian(nn.Module):
 
         seed, offset = (0, 0)
         if training and noise is None:
-            noise = rng.captured_noise('normal', (rows.shape[0], L), rows)   # None unless a HIP graph is capturing
+            noise = rng.captured_noise('normal', (rows.shape[0], rows.shape[1] // 2), rows)   # None unless a HIP graph is capturing
         if training and noise is None:
             seed, offset = rng.next_call()
-        z, logvar, kl, means = F_.gauss_reparam_kl(rows, noise=noise, eps_tol=EPS_TOL, training=training, seed=seed,
-                                                   offset=offset, row0=self.row_offset, mean_scale=self.mean_scale)
-        logvar = logvar.reshape(out_shape)
+        z, _, kl, means = F_.gauss_reparam_kl(rows, noise=noise, eps_tol=EPS_TOL, training=training, seed=seed,
+                                              offset=offset, row0=self.row_offset, mean_scale=self.mean_scale,
+                                              want_logvar=False)
         z = z.reshape(out_shape) if training else mu
-        logvar._vae_amd_kl = (kl.reshape(kl_shape), mu)   # consumed by kl(); invisible to dict consumers
-        logvar._vae_amd_means = means
-        return z, {'z': z, 'mu': mu, 'logvar': logvar}
+        g = LazyParams({'z': z, 'mu': mu})
+        # the reference's own op (isotropic_gaussian.py:124-125), run only if somebody reads the entry
+        g.set_lazy('logvar', lambda: torch.narrow(logits, dim2slice, L, L) + EPS_TOL)
+        g._vae_amd_kl = (kl.reshape(kl_shape), mu)      # consumed by kl(); invisible to dict consumers
+        g._vae_amd_means = means
+        return z, g
 
     def forward(self, logits, force=False, noise=None):
         z, gauss_params = self.reparmeterize(logits, force=force, noise=noise)
-        means = gauss_params['logvar']._vae_amd_means.to(logits.dtype)
+        means = gauss_params._vae_amd_means.to(logits.dtype)
         gauss_params['mu_mean'] = means[0]
         gauss_params['logvar_mean'] = means[1]
         return z, {'z': z, 'logits': logits, 'gaussian': gauss_params}
@@ -106,15 +112,22 @@ class IsotropicGaussian(nn.Module):
         if noise is None:
             noise = rng.captured_noise('normal', (S, logits.shape[0], L), logits)
         seed, offset = (0, 0) if noise is not None else rng.next_calls(S)
-        z, logvar, kl, means = F_.gauss_reparam_multi(logits, S, noise=noise, eps_tol=EPS_TOL, seed=seed, offset=offset,
-                                                      row0=self.row_offset, mean_scale=self.mean_scale)
+        z, _, kl, means = F_.gauss_reparam_multi(logits, S, noise=noise, eps_tol=EPS_TOL, seed=seed, offset=offset,
+                                                 row0=self.row_offset, mean_scale=self.mean_scale, want_logvar=False)
         mu = torch.narrow(logits, -1, 0, L)
-        logvar._vae_amd_kl = (kl, mu)
-        logvar._vae_amd_means = means
+        shared = {}
+
+        def logvar_once():      # one tensor shared by the S parameter sets, as mu is
+            if 'v' not in shared:
+                shared['v'] = torch.narrow(logits, -1, L, L) + EPS_TOL
+            return shared['v']
         means = means.to(logits.dtype)
         z_list, params_list = [], []
         for i in range(S):
-            g = {'z': z[i], 'mu': mu, 'logvar': logvar, 'mu_mean': means[0], 'logvar_mean': means[1]}
+            g = LazyParams({'z': z[i], 'mu': mu})
+            g.set_lazy('logvar', logvar_once)
+            g._vae_amd_kl = (kl, mu)
+            g['mu_mean'], g['logvar_mean'] = means[0], means[1]
             z_list.append(z[i])
             params_list.append({'z': z[i], 'logits': logits, 'gaussian': g})
         return z_list, params_list
@@ -122,7 +135,11 @@ class IsotropicGaussian(nn.Module):
     def kl(self, dist_a, prior=None):
         g = dist_a['gaussian']
         if prior is None:
-            fused = getattr(g['logvar'], '_vae_amd_kl', None)
+            # the KL the forward launch already produced: kept on the params dict (single / multi / Concat forward)
+            # or on the logvar tensor (fused VRNN / conditioned-prior step)
+            fused = getattr(g, '_vae_amd_kl', None)
+            if fused is None and not (isinstance(g, LazyParams) and g.is_pending('logvar')):
+                fused = getattr(g['logvar'], '_vae_amd_kl', None)
             if fused is not None and fused[1] is g['mu']:
                 return fused[0]
             return F_.gauss_kl(g['mu'], g['logvar'])
