@@ -82,6 +82,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=B_PER_GPU, help='samples per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--main-only', action='store_true',
+                    help='only the timed region (profiling runs: no Philox variant, no module path, no CPU leg)')
     ap.add_argument('--two-pass', action='store_true', help='separate NLL forward and backward kernels')
     ap.add_argument('--materialize-logvar', action='store_true',
                     help="also write params['gaussian']['logvar'] in the forward (the module classes produce it on first "
@@ -235,7 +237,7 @@ def main():
     # the production form of the same step (the module classes' default): eps drawn inside the kernels from
     # Philox4x32-10 instead of read from HBM -- reported beside the main figure, never as `value`
     philox_variant = None
-    if world == 1 and not philox:
+    if world == 1 and not philox and not args.main_only:
         noise_arg[0] = None
         for _ in range(args.warmup):
             step()
@@ -258,7 +260,7 @@ def main():
     # the same step through the drop-in classes (autograd Functions, torch allocator): not the timed region,
     # reported beside it so the cost of the Python boundary is visible
     module_path = None
-    if world == 1:
+    if world == 1 and not args.main_only:
         from vae_amd.reparameterizers import IsotropicGaussian
         from vae_amd.elbo import loss_function
         mod = IsotropicGaussian({'continuous_size': 2 * L, 'cuda': True, 'half': False})
@@ -334,7 +336,7 @@ def main():
             'module_path': module_path,
             'philox_variant': philox_variant,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.main_only:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist is not None:
