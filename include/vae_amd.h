@@ -118,14 +118,16 @@ int vae_gauss_pair_bwd(const void* enc_logits, int64_t stride_enc, const void* p
  * reference draws U on the CPU and copies it to the device every step), :281-304
  * (h = (y == rowmax(y)), multi-hot on ties; z_hard = (h - y).detach() + y).
  *   logits [B, K] rows `row_stride` apart; unif [B, K] uniform draws or NULL
- *   (Philox keyed by (seed, offset, row0 + row, col)); y, z_hard, log_q_z [B, K].
+ *   (Philox keyed by (seed, offset, row0 + row, col)); y, z_hard, log_q_z [B, K], each may be
+ *   NULL (not written; at least one is given; log_q_z alone skips the draw and the softmax).
  *   K <= VAE_MAX_SOFTMAX_ROW.                                                     */
 int vae_gumbel_fwd(const void* logits, int64_t row_stride, const void* unif, void* y, int64_t y_stride, void* z_hard,
                    int64_t z_hard_stride, void* log_q_z,
                    int64_t B, int64_t K, float tau, uint64_t seed, uint64_t offset, int64_t row0, int dtype,
                    vae_stream_t stream);
 /* glogits [B, K] from the grads of y, z_hard (straight-through: passes to y) and
- * log_q_z (each may be NULL), using the saved outputs y and log_q_z.              */
+ * log_q_z (each may be NULL; all NULL writes zeros), using the saved outputs y (needed for gy / gz_hard) and
+ * log_q_z (needed for glog_q_z).                                                  */
 int vae_gumbel_bwd(const void* y, int64_t y_stride, const void* log_q_z, const void* gy, int64_t gy_stride,
                    const void* gz_hard, int64_t gz_hard_stride, const void* glog_q_z, void* glogits,
                    int64_t glogits_stride, int64_t B, int64_t K, float tau, int dtype, vae_stream_t stream);
@@ -141,7 +143,8 @@ int vae_categorical_kl_bwd(const void* log_q, int64_t stride_q, const void* log_
  * reparameterizers/bernoulli.py:126-136 via torch/distributions/relaxed_bernoulli.py:104-112
  * (p = clamp(sigmoid(l)), u = clamp(U), y = sigmoid((log u - log1p(-u) + log p - log1p(-p))/tau)),
  * bernoulli.py:111-124 (hard = y >= 0.5; z_hard = (hard - y).detach() + y).
- *   logits [B, K] rows `row_stride` apart; unif [B, K] or NULL (Philox); y, z_hard [B, K].  */
+ *   logits [B, K] rows `row_stride` apart; unif [B, K] or NULL (Philox); y, z_hard [B, K]
+ *   (z_hard may be NULL: not written).                                                    */
 int vae_bernoulli_fwd(const void* logits, int64_t row_stride, const void* unif, void* y, int64_t y_stride, void* z_hard,
                       int64_t z_hard_stride, int64_t B,
                       int64_t K, float tau, uint64_t seed, uint64_t offset, int64_t row0, int dtype,

@@ -90,6 +90,8 @@ def gumbel(B, K, philox=False):
     u = None if philox else U
     cfg = 'B=%d K=%d f32%s' % (B, K, ' philox' if philox else '')
     timeit('gumbel_fwd', cfg, lambda: call('vae_gumbel_fwd', ptr(logits), K, ptr(u), ptr(y), 0, ptr(zh), 0, ptr(lq), B, K, 0.7, 1, 1, 0, 0, st), B * ((16 if philox else 20) * K))
+    timeit('gumbel_fwd (y only: training)', cfg, lambda: call('vae_gumbel_fwd', ptr(logits), K, ptr(u), ptr(y), 0, None, 0, None, B, K, 0.7, 1, 1, 0, 0, st), B * ((8 if philox else 12) * K))
+    timeit('gumbel_fwd (log_q_z only)', cfg, lambda: call('vae_gumbel_fwd', ptr(logits), K, None, None, 0, None, 0, ptr(lq), B, K, 0.7, 1, 1, 0, 0, st), B * 8 * K)
     timeit('gumbel_bwd (gy only)', cfg, lambda: call('vae_gumbel_bwd', ptr(y), 0, ptr(lq), ptr(gy), 0, None, 0, None, ptr(gl), 0, B, K, 0.7, 0, st), B * 12 * K)
     kl, gkl = T(B, kind='e'), T(B)
     timeit('categorical_kl_fwd', cfg, lambda: call('vae_categorical_kl_fwd', ptr(lq), K, ptr(logits), K, ptr(kl), B, K, 0, st), B * (8 * K + 4))

@@ -200,3 +200,46 @@ def test_bernoulli_vs_oracle(B, K):
                        p0['discrete']['z_hard'].detach().round()[decided])
     close(k1, k0, rtol=1e-5, atol=1e-5)
     close(g1, g0, rtol=1e-4, atol=1e-5)
+
+
+def test_training_forward_writes_the_soft_sample_only():
+    """GumbelSoftmax / Bernoulli in training: z_hard (and log_q_z) keep their place in the params dict but are
+    produced on first read, with the bits the eager (eval-mode) launch writes and with gradients to the logits."""
+    from vae_amd.lazy import LazyParams
+    from vae_amd.reparameterizers import GumbelSoftmax, Bernoulli
+    from vae_amd import functional as F_
+    torch.manual_seed(8)
+    B, K = 96, 40
+    logits, U = torch.randn(B, K), torch.rand(B, K)
+    lg = logits.to(DEV).requires_grad_(True)
+
+    m = GumbelSoftmax({'discrete_size': K, 'cuda': True, 'half': False})
+    m.train()
+    z, params = m(lg, noise=U.to(DEV))
+    d = params['discrete']
+    assert isinstance(d, LazyParams) and d.is_pending('z_hard') and d.is_pending('log_q_z')
+    assert list(d) == ['z_hard', 'logits', 'log_q_z', 'tau_scalar']
+    y_e, zh_e, lq_e = F_.gumbel_softmax(lg, U.to(DEV), tau=1.0)            # the eager launch: all three outputs
+    assert torch.equal(z, y_e)
+    assert torch.equal(d['z_hard'], zh_e) and torch.equal(d['log_q_z'], lq_e)
+    y0, p0 = O.gumbel_forward(logits, U, tau=1.0, training=True)
+    assert torch.equal((d['z_hard'].cpu() == 1), (p0['discrete']['z_hard'] == 1))
+    w = torch.randn(B, K)
+    lc = logits.clone().requires_grad_(True)
+    y0, p0 = O.gumbel_forward(lc, U, tau=1.0, training=True)
+    (g0,) = torch.autograd.grad((p0['discrete']['z_hard'] * w).sum() + (p0['discrete']['log_q_z'] * w).sum()
+                                + (y0 * w).sum(), lc)
+    wd = w.to(DEV)
+    (g1,) = torch.autograd.grad((d['z_hard'] * wd).sum() + (d['log_q_z'] * wd).sum() + (z * wd).sum(), lg)
+    close(g1, g0, rtol=1e-4, atol=1e-5)
+
+    mb = Bernoulli({'discrete_size': K, 'cuda': True, 'half': False, 'epochs': 10})
+    mb.train()
+    zb, pb = mb(lg, noise=U.to(DEV))
+    db = pb['discrete']
+    assert isinstance(db, LazyParams) and db.is_pending('z_hard') and list(db) == ['z_hard', 'logits', 'tau_scalar']
+    y_e, zh_e = F_.relaxed_bernoulli(lg, U.to(DEV), tau=1.0)
+    assert torch.equal(zb, y_e) and torch.equal(db['z_hard'], zh_e)
+    (gb,) = torch.autograd.grad((db['z_hard'] * wd).sum(), lg)
+    (ge,) = torch.autograd.grad((zh_e * wd).sum(), lg)
+    close(gb, ge, rtol=1e-5, atol=1e-7)

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kBlock) void bernoulli_fwd_kernel(
             zh[i] = add_rn(to_f32(from_f32<T>(sub_rn(h, y[i]))), y[i]);
           }
           store_vec<T, V>(y_out + row * y_stride + (int64_t)j * V, y);
-          store_vec<T, V>(zh_out + row * zh_stride + (int64_t)j * V, zh);
+          if (zh_out) store_vec<T, V>(zh_out + row * zh_stride + (int64_t)j * V, zh);
         }
       }
     }
@@ -250,7 +250,7 @@ int vae_bernoulli_fwd(const void* logits, int64_t row_stride, const void* unif, 
   if (B == 0) return VAE_OK;
   if (y_stride == 0) y_stride = K;
   if (z_hard_stride == 0) z_hard_stride = K;
-  if (!logits || !y || !z_hard || row_stride < K || y_stride < K || z_hard_stride < K) return VAE_ERR_ARG;
+  if (!logits || !y || row_stride < K || y_stride < K || z_hard_stride < K) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32) return bern_fwd_dispatch<float>(logits, row_stride, unif, y, y_stride, z_hard, z_hard_stride, B, K, tau, seed, offset, row0, st);
   if (dtype == VAE_BF16) return bern_fwd_dispatch<bf16_t>(logits, row_stride, unif, y, y_stride, z_hard, z_hard_stride, B, K, tau, seed, offset, row0, st);

@@ -39,24 +39,46 @@ __global__ __launch_bounds__(kBlock) void gumbel_fwd_kernel(
     const int64_t r = live ? row : B - 1;  // dead lane groups shadow the last row (no stores)
     float l[U][V], u[U][V];
     load_chunk<T, V, U>(logits + r * row_stride, sub, G, nvec, l);
-    if (unif) load_chunk<T, V, U>(unif + r * K, sub, G, nvec, u);
+    if (unif && (y_out || zh_out)) load_chunk<T, V, U>(unif + r * K, sub, G, nvec, u);
+
+    // Each output may be absent (kernel-uniform): the module classes write only what the step reads -- y in
+    // training -- and produce z_hard / log_q_z on first read (vae_amd/lazy.py).
+    const bool want_lq = lq_out != nullptr;
+    const bool want_soft = y_out != nullptr || zh_out != nullptr;
 
     // ---- log_q_z = (l - max) - log(sum exp(l - max))
-    float m1 = kNegInf;
+    float m1 = kNegInf, lse = 0.f;
+    if (want_lq) {
 #pragma unroll
-    for (int k = 0; k < U; ++k)
-      if (sub + k * G < nvec)
+      for (int k = 0; k < U; ++k)
+        if (sub + k * G < nvec)
 #pragma unroll
-        for (int i = 0; i < V; ++i) m1 = fmaxf(m1, l[k][i]);
-    m1 = row_max(m1, G);
-    float s1 = 0.f;
+          for (int i = 0; i < V; ++i) m1 = fmaxf(m1, l[k][i]);
+      m1 = row_max(m1, G);
+      float s1 = 0.f;
 #pragma unroll
-    for (int k = 0; k < U; ++k)
-      if (sub + k * G < nvec)
+      for (int k = 0; k < U; ++k)
+        if (sub + k * G < nvec)
 #pragma unroll
-        for (int i = 0; i < V; ++i) s1 += expf(sub_rn(l[k][i], m1));
-    s1 = row_sum(s1, G);
-    const float lse = logf(s1);
+          for (int i = 0; i < V; ++i) s1 += expf(sub_rn(l[k][i], m1));
+      s1 = row_sum(s1, G);
+      lse = logf(s1);
+    }
+    if (!want_soft) {
+      if (live) {
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          const int j = sub + k * G;
+          if (j < nvec) {
+            float lq[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) lq[i] = sub_rn(sub_rn(l[k][i], m1), lse);
+            store_vec<T, V>(lq_out + row * K + (int64_t)j * V, lq);
+          }
+        }
+      }
+      continue;
+    }
 
     // ---- x = (l + g)/tau + eps, g = -log(-log(U + eps) + eps): every op rounds on its own
     float x[U][V];
@@ -112,9 +134,9 @@ __global__ __launch_bounds__(kBlock) void gumbel_fwd_kernel(
             zh[i] = add_rn(to_f32(from_f32<T>(sub_rn(h, x[k][i]))), x[k][i]);  // (h - y).detach() + y
             lq[i] = sub_rn(sub_rn(l[k][i], m1), lse);
           }
-          store_vec<T, V>(y_out + row * y_stride + (int64_t)j * V, x[k]);
-          store_vec<T, V>(zh_out + row * zh_stride + (int64_t)j * V, zh);
-          store_vec<T, V>(lq_out + row * K + (int64_t)j * V, lq);
+          if (y_out) store_vec<T, V>(y_out + row * y_stride + (int64_t)j * V, x[k]);
+          if (zh_out) store_vec<T, V>(zh_out + row * zh_stride + (int64_t)j * V, zh);
+          if (want_lq) store_vec<T, V>(lq_out + row * K + (int64_t)j * V, lq);
         }
       }
     }
@@ -345,7 +367,8 @@ int vae_gumbel_fwd(const void* logits, int64_t row_stride, const void* unif, voi
   if (B == 0) return VAE_OK;
   if (y_stride == 0) y_stride = K;
   if (z_hard_stride == 0) z_hard_stride = K;
-  if (!logits || !y || !z_hard || !log_q_z || row_stride < K || y_stride < K || z_hard_stride < K) return VAE_ERR_ARG;
+  if (!logits || (!y && !z_hard && !log_q_z) || row_stride < K || y_stride < K || z_hard_stride < K)
+    return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32)
     return gumbel_fwd_dispatch<float>(logits, row_stride, unif, y, y_stride, z_hard, z_hard_stride, log_q_z, B, K, tau, seed, offset, row0, st);
@@ -364,8 +387,8 @@ int vae_gumbel_bwd(const void* y, int64_t y_stride, const void* log_q_z, const v
   if (gy_stride == 0) gy_stride = K;
   if (gz_hard_stride == 0) gz_hard_stride = K;
   if (glogits_stride == 0) glogits_stride = K;
-  if (!y || !log_q_z || !glogits || y_stride < K || gy_stride < K || gz_hard_stride < K || glogits_stride < K)
-    return VAE_ERR_ARG;
+  if (!glogits || y_stride < K || gy_stride < K || gz_hard_stride < K || glogits_stride < K) return VAE_ERR_ARG;
+  if (((gy || gz_hard) && !y) || (glog_q_z && !log_q_z)) return VAE_ERR_ARG;   // no gradient at all: zeros
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32) return gumbel_bwd_dispatch<float>(y, y_stride, log_q_z, gy, gy_stride, gz_hard, gz_hard_stride, glog_q_z, glogits,
                                       glogits_stride, B, K, tau, st);

@@ -336,38 +336,53 @@ def elbo_combine(nll_, kld=None, add=None, mi=None, kl_beta=1.0, inv_count=None)
 # GumbelSoftmax
 # --------------------------------------------------------------------------------------
 class _Gumbel(torch.autograd.Function):
+    """want = (y, z_hard, log_q_z) flags: outputs that are not wanted are not written (empty placeholders)."""
+
     @staticmethod
-    def forward(ctx, logits, unif, tau, seed, offset, row0):
+    def forward(ctx, logits, unif, tau, seed, offset, row0, want):
         ctx.set_materialize_grads(False)
         dev = check_device(logits, unif)
         B, K = logits.shape
-        y = torch.empty((B, K), dtype=logits.dtype, device=dev)
-        zh = torch.empty_like(y)
-        lq = torch.empty_like(y)
+        new = lambda w: torch.empty((B, K), dtype=logits.dtype, device=dev) if w else None
+        y, zh, lq = new(want[0]), new(want[1]), new(want[2])
         with _Guard(dev):
             call('vae_gumbel_fwd', ptr(logits), logits.stride(0), ptr(unif), ptr(y), 0, ptr(zh), 0, ptr(lq), B, K, tau,
                  seed & _MASK64, offset & _MASK64, row0, dtype_code(logits), stream_ptr(dev))
         ctx.save_for_backward(y, lq)
         ctx.tau = tau
-        return y, zh, lq
+        outs, nd = [], []
+        for t in (y, zh, lq):
+            if t is None:
+                t = logits.new_empty((0,))
+                nd.append(t)
+            outs.append(t)
+        if nd:
+            ctx.mark_non_differentiable(*nd)
+        return tuple(outs)
 
     @staticmethod
     def backward(ctx, gy, gzh, glq):
-        if gy is None and gzh is None and glq is None:
-            return None, None, None, None, None, None
         y, lq = ctx.saved_tensors
-        dev = y.device
-        B, K = y.shape
+        if y is None:
+            gy = gzh = None
+        if lq is None:
+            glq = None
+        if gy is None and gzh is None and glq is None:
+            return None, None, None, None, None, None, None
+        ref = y if y is not None else lq
+        dev = ref.device
+        B, K = ref.shape
         gy, gzh, glq = _dense(gy), _dense(gzh), _dense(glq)
-        gl = torch.empty_like(y)
+        gl = torch.empty_like(ref)
         with _Guard(dev):
             call('vae_gumbel_bwd', ptr(y), 0, ptr(lq), ptr(gy), 0, ptr(gzh), 0, ptr(glq), ptr(gl), 0, B, K, ctx.tau,
-                 dtype_code(y), stream_ptr(dev))
-        return gl, None, None, None, None, None
+                 dtype_code(ref), stream_ptr(dev))
+        return gl, None, None, None, None, None, None
 
 
-def gumbel_softmax(logits, unif=None, tau=1.0, seed=0, offset=0, row0=0):
-    """logits [..., K] -> (y soft sample, z_hard straight-through, log_q_z), all [..., K].
+def gumbel_softmax(logits, unif=None, tau=1.0, seed=0, offset=0, row0=0, want=(True, True, True)):
+    """logits [..., K] -> (y soft sample, z_hard straight-through, log_q_z), all [..., K]; an entry of `want`
+    set False leaves that output unwritten (returned as None).
 
     Reference: reparameterizers/gumbel.py:110-124, :257-304.  `unif` is the torch.rand draw of :269
     (None: Philox in the kernel)."""
@@ -375,8 +390,14 @@ def gumbel_softmax(logits, unif=None, tau=1.0, seed=0, offset=0, row0=0):
     rows = _rows(logits)
     if unif is not None:
         unif = unif.reshape(rows.shape).to(rows.dtype).contiguous()
-    y, zh, lq = _Gumbel.apply(rows, unif, float(tau), int(seed), int(offset), int(row0))
-    return y.reshape(shape), zh.reshape(shape), lq.reshape(shape)
+    want = tuple(bool(w) for w in want)
+    outs = _Gumbel.apply(rows, unif, float(tau), int(seed), int(offset), int(row0), want)
+    return tuple(o.reshape(shape) if w else None for o, w in zip(outs, want))
+
+
+def log_softmax_rows(logits):
+    """log_q_z = log_softmax(logits, -1) (gumbel.py:119) alone: the Gumbel kernel with only that output."""
+    return gumbel_softmax(logits, None, 1.0, want=(False, False, True))[2]
 
 
 class _CategoricalKL(torch.autograd.Function):
@@ -418,23 +439,28 @@ def categorical_kl(log_q, log_p):
 # --------------------------------------------------------------------------------------
 class _Bernoulli(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, unif, tau, seed, offset, row0):
+    def forward(ctx, logits, unif, tau, seed, offset, row0, want_hard=True):
         ctx.set_materialize_grads(False)
         dev = check_device(logits, unif)
         B, K = logits.shape
         y = torch.empty((B, K), dtype=logits.dtype, device=dev)
-        zh = torch.empty_like(y)
+        zh = torch.empty_like(y) if want_hard else None
         with _Guard(dev):
             call('vae_bernoulli_fwd', ptr(logits), logits.stride(0), ptr(unif), ptr(y), 0, ptr(zh), 0, B, K, tau,
                  seed & _MASK64, offset & _MASK64, row0, dtype_code(logits), stream_ptr(dev))
         ctx.save_for_backward(logits, y)
         ctx.tau = tau
+        if zh is None:
+            zh = logits.new_empty((0,))
+            ctx.mark_non_differentiable(zh)
         return y, zh
 
     @staticmethod
     def backward(ctx, gy, gzh):
+        if gzh is not None and gzh.numel() == 0:
+            gzh = None
         if gy is None and gzh is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         logits, y = ctx.saved_tensors
         dev = y.device
         B, K = y.shape
@@ -442,17 +468,18 @@ class _Bernoulli(torch.autograd.Function):
         with _Guard(dev):
             call('vae_bernoulli_bwd', ptr(logits), logits.stride(0), ptr(y), 0, ptr(_dense(gy)), 0, ptr(_dense(gzh)), 0,
                  ptr(gl), 0, B, K, ctx.tau, dtype_code(y), stream_ptr(dev))
-        return gl, None, None, None, None, None
+        return gl, None, None, None, None, None, None
 
 
-def relaxed_bernoulli(logits, unif=None, tau=1.0, seed=0, offset=0, row0=0):
-    """logits [..., K] -> (y relaxed sample, z_hard straight-through).  bernoulli.py:111-136."""
+def relaxed_bernoulli(logits, unif=None, tau=1.0, seed=0, offset=0, row0=0, want_hard=True):
+    """logits [..., K] -> (y relaxed sample, z_hard straight-through or None unless `want_hard`).
+    bernoulli.py:111-136."""
     shape = logits.shape
     rows = _rows(logits)
     if unif is not None:
         unif = unif.reshape(rows.shape).to(rows.dtype).contiguous()
-    y, zh = _Bernoulli.apply(rows, unif, float(tau), int(seed), int(offset), int(row0))
-    return y.reshape(shape), zh.reshape(shape)
+    y, zh = _Bernoulli.apply(rows, unif, float(tau), int(seed), int(offset), int(row0), bool(want_hard))
+    return y.reshape(shape), (zh.reshape(shape) if want_hard else None)
 
 
 class _BernoulliKL(torch.autograd.Function):
@@ -751,13 +778,15 @@ class _ConcatLeaves(torch.autograd.Function):
                     i_off, o_off = i_off + 2 * L, o_off + L
                 else:
                     K, tau = spec[1], spec[2]
-                    other = new(B, K)          # the output that does NOT go into the concatenated sample
-                    y_ptr, y_s, zh_ptr, zh_s = (_poff(zcat, o_off), W_out, ptr(other), K) if training else \
+                    # the output that does NOT go into the concatenated sample: y in eval; in training it would be
+                    # z_hard, which -- like log_q_z -- the module class produces on first read instead
+                    other = logits.new_empty((0,)) if training else new(B, K)
+                    y_ptr, y_s, zh_ptr, zh_s = (_poff(zcat, o_off), W_out, None, K) if training else \
                         (ptr(other), K, _poff(zcat, o_off), W_out)
                     if kind == 'gumbel':
-                        lq = new(B, K)
-                        call('vae_gumbel_fwd', _poff(logits, i_off), rs, ptr(noise), y_ptr, y_s, zh_ptr, zh_s, ptr(lq),
-                             B, K, tau, seed & _MASK64, offset & _MASK64, row0, dt, st)
+                        lq = logits.new_empty((0,)) if training else new(B, K)
+                        call('vae_gumbel_fwd', _poff(logits, i_off), rs, ptr(noise), y_ptr, y_s, zh_ptr, zh_s,
+                             None if training else ptr(lq), B, K, tau, seed & _MASK64, offset & _MASK64, row0, dt, st)
                         outs += [other, lq]
                     else:
                         call('vae_bernoulli_fwd', _poff(logits, i_off), rs, ptr(noise), y_ptr, y_s, zh_ptr, zh_s, B, K,
@@ -804,12 +833,14 @@ class _ConcatLeaves(torch.autograd.Function):
                     K, tau = spec[1], spec[2]
                     other, g_other = outs[1 + k], _dense(gex[k])
                     gc_p, gc_s = gslice(o_off)
-                    if training:   # y lives in zcat, z_hard is `other`
-                        y_p, y_s, gy_p, gy_s, gzh_p, gzh_s = _poff(zcat, o_off), W_out, gc_p, gc_s, ptr(g_other), K
+                    if training:   # y lives in zcat; z_hard was not produced here
+                        y_p, y_s, gy_p, gy_s, gzh_p, gzh_s = _poff(zcat, o_off), W_out, gc_p, gc_s, None, K
                     else:          # z_hard lives in zcat, y is `other`
                         y_p, y_s, gy_p, gy_s, gzh_p, gzh_s = ptr(other), K, ptr(g_other), K, gc_p, gc_s
                     if kind == 'gumbel':
                         lq, glq = outs[2 + k], _dense(gex[k + 1])
+                        if training:
+                            lq = glq = None
                         call('vae_gumbel_bwd', y_p, y_s, ptr(lq), gy_p, gy_s, gzh_p, gzh_s, ptr(glq),
                              _poff(glogits, i_off), W_in, B, K, tau, dt, st)
                         k += 2
@@ -824,7 +855,8 @@ class _ConcatLeaves(torch.autograd.Function):
 def concat_leaves(logits, specs, training, noises, seeds, row0=0):
     """Run kernel-backed Concat children over one [B, sum(in)] logits buffer.  Returns the flat tuple
     (zcat, then per child: gauss -> (empty placeholder), kl, means[2]; gumbel -> other, log_q_z; bern -> other), where
-    `other` is z_hard in training (y went into zcat) and y in eval (z_hard went into zcat)."""
+    `other` is y in eval (z_hard went into zcat) and an empty placeholder in training (y went into zcat; z_hard and
+    log_q_z are then produced on first read by the module classes)."""
     logits = _rows(logits)
     B = logits.shape[0]
     fixed = []

@@ -70,3 +70,19 @@ class LazyParams(dict):
 
     def __reduce__(self):
         return (dict, (dict(self.items()),))     # pickles / deep-copies as a plain dict
+
+
+def hard_from_soft_max(y):
+    """Straight-through one-hot of a soft sample, from the sample alone (gumbel.py:296-301): 1 where y equals its
+    row maximum (multi-hot on exact ties), value of the mask, gradient of y.  Plain elementwise torch ops on the
+    device: the same IEEE operations the fused kernel performs, so the bits are the same."""
+    yd = y.detach()
+    h = (yd == yd.amax(-1, keepdim=True)).to(y.dtype)
+    return (h - yd) + y
+
+
+def hard_from_soft_threshold(y):
+    """Straight-through 0/1 of a relaxed Bernoulli sample (bernoulli.py:111-124): 1 where y >= 0.5."""
+    yd = y.detach()
+    h = (yd >= 0.5).to(y.dtype)
+    return (h - yd) + y

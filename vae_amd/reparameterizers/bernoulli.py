@@ -8,6 +8,7 @@ import torch.distributions as D
 
 from .. import functional as F_
 from .. import rng
+from ..lazy import LazyParams, hard_from_soft_threshold
 
 
 class Bernoulli(nn.Module):
@@ -61,12 +62,12 @@ class Bernoulli(nn.Module):
                 * (1 + math.cos(math.pi * -1 / self.last_epoch)) / 2
             self.tau = np.clip(updated_tau, self.clip_min, self.max_temp)
 
-    def reparmeterize(self, logits, noise=None):
+    def reparmeterize(self, logits, noise=None, want_hard=True):
         if noise is None:
             noise = rng.captured_noise('uniform', logits.shape, logits)   # None unless a HIP graph is capturing
         seed, offset = (0, 0) if noise is not None else rng.next_call()
         return F_.relaxed_bernoulli(logits, unif=noise, tau=float(self.tau), seed=seed, offset=offset,
-                                    row0=self.row_offset)
+                                    row0=self.row_offset, want_hard=want_hard)
 
     def mutual_info_analytic(self, params, eps=1e-9):
         raise NotImplementedError
@@ -88,9 +89,15 @@ class Bernoulli(nn.Module):
 
     def forward(self, logits, force=False, noise=None):
         self.anneal()
-        z, z_hard = self.reparmeterize(logits, noise=noise)
-        params = {'z_hard': z_hard, 'logits': logits, 'tau_scalar': self.tau}
         self.iteration += 1
-        if self.training or force:
-            return z, {'z': z, 'logits': logits, 'discrete': params}
-        return z_hard, {'z': z, 'logits': logits, 'discrete': params}
+        if not (self.training or force):
+            z, z_hard = self.reparmeterize(logits, noise=noise)
+            params = {'z_hard': z_hard, 'logits': logits, 'tau_scalar': self.tau}
+            return z_hard, {'z': z, 'logits': logits, 'discrete': params}
+        # training: only the relaxed sample is written; z_hard is produced on first read (vae_amd/lazy.py)
+        z, _ = self.reparmeterize(logits, noise=noise, want_hard=False)
+        params = LazyParams()
+        params.set_lazy('z_hard', lambda: hard_from_soft_threshold(z))
+        params['logits'] = logits
+        params['tau_scalar'] = self.tau
+        return z, {'z': z, 'logits': logits, 'discrete': params}

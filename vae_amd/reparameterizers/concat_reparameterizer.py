@@ -7,7 +7,7 @@ import torch.nn as nn
 
 from .. import functional as F_
 from .. import rng
-from ..lazy import LazyParams
+from ..lazy import LazyParams, hard_from_soft_max, hard_from_soft_threshold
 from .bernoulli import Bernoulli
 from .gumbel import GumbelSoftmax
 from .isotropic_gaussian import EPS_TOL, IsotropicGaussian
@@ -87,13 +87,24 @@ class ConcatReparameterizer(nn.Module):
             else:
                 logits_i = logits[:, i_off:i_off + n_out]
                 other = outs[k]
-                y, z_hard = (z_i, other) if training else (other, z_i)
-                d = {'z_hard': z_hard, 'logits': logits_i, 'tau_scalar': child.tau}
+                y, z_hard = (z_i, None) if training else (other, z_i)
+                d = LazyParams()
+                if training:   # the launch wrote y only (see GumbelSoftmax.forward / Bernoulli.forward)
+                    d.set_lazy('z_hard', (lambda yy=y: hard_from_soft_max(yy)) if kind == 'gumbel' else
+                               (lambda yy=y: hard_from_soft_threshold(yy)))
+                else:
+                    d['z_hard'] = z_hard
+                d['logits'] = logits_i
                 if kind == 'gumbel':
-                    d = {'z_hard': z_hard, 'logits': logits_i, 'log_q_z': outs[k + 1], 'tau_scalar': child.tau}
+                    if training:
+                        d.set_lazy('log_q_z', lambda li=logits_i: F_.log_softmax_rows(li))
+                    else:
+                        d['log_q_z'] = outs[k + 1]
+                    d['tau_scalar'] = child.tau
                     params = {'z': y, 'discrete': d}
                     k += 2
                 else:
+                    d['tau_scalar'] = child.tau
                     params = {'z': y, 'logits': logits_i, 'discrete': d}
                     k += 1
                 child.iteration += 1

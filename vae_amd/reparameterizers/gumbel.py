@@ -2,7 +2,8 @@
 fused HIP kernel: log_softmax, Gumbel noise, temperature softmax, the == rowmax hard mask
 (multi-hot on ties) and the straight-through sample in one launch.  The reference draws U with
 torch.rand on the CPU and copies [B,K] to the device every step (:269-273); here U is either
-injected (`noise=`) or drawn by Philox inside the kernel."""
+injected (`noise=`) or drawn by Philox inside the kernel.  In training only the soft sample is written; `z_hard` and
+`log_q_z` are produced on first read (vae_amd/lazy.py), with the values the eager launch gives."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -11,6 +12,7 @@ import torch.distributions as D
 
 from .. import functional as F_
 from .. import rng
+from ..lazy import LazyParams, hard_from_soft_max
 
 
 class GumbelSoftmax(nn.Module):
@@ -55,13 +57,13 @@ class GumbelSoftmax(nn.Module):
             rate = -self.anneal_rate * self.iteration
             self.tau = np.maximum(self.tau0 * np.exp(rate), self.min_temp)
 
-    def reparmeterize(self, logits, noise=None):
+    def reparmeterize(self, logits, noise=None, want=(True, True, True)):
         assert self.dim in (-1, logits.dim() - 1), "the HIP path reduces over the last dim"
         if noise is None:
             noise = rng.captured_noise('uniform', logits.shape, logits)   # None unless a HIP graph is capturing
         seed, offset = (0, 0) if noise is not None else rng.next_call()
         return F_.gumbel_softmax(logits, unif=noise, tau=float(self.tau), seed=seed, offset=offset,
-                                 row0=self.row_offset)
+                                 row0=self.row_offset, want=want)
 
     def mutual_info_monte_carlo(self, params, eps=1e-9):
         # gumbel.py:153-157: sum p_z log q(z|xhat) - sum p_z log q(z|x) with p_z = softmax(logits) = exp(log_q_z),
@@ -81,21 +83,30 @@ class GumbelSoftmax(nn.Module):
         return self.config['discrete_mut_info'] * self.mutual_info_monte_carlo(params)
 
     def kl(self, dist_a, prior=None):
-        log_q = dist_a['discrete']['log_q_z']
         if prior is None:
             # the reference builds the "prior" from the same log_q_z (gumbel.py:243): KL(q||q), exactly 0
-            # in value and gradient; no launch is spent on it.
-            return torch.zeros(log_q.shape[:-1], dtype=log_q.dtype, device=log_q.device)
-        return F_.categorical_kl(log_q, prior['discrete']['log_q_z'])
+            # in value and gradient; no launch is spent on it (nor on producing log_q_z).
+            ref = dist_a['discrete']['logits']
+            return torch.zeros(ref.shape[:-1], dtype=ref.dtype, device=ref.device)
+        return F_.categorical_kl(dist_a['discrete']['log_q_z'], prior['discrete']['log_q_z'])
 
     def log_likelihood(self, z, params):
         return D.OneHotCategorical(logits=params['discrete']['logits']).log_prob(z)
 
     def forward(self, logits, force=False, noise=None):
         self.anneal()  # anneal first
-        z, z_hard, log_q_z = self.reparmeterize(logits, noise=noise)
-        params = {'z_hard': z_hard, 'logits': logits, 'log_q_z': log_q_z, 'tau_scalar': self.tau}
+        soft = bool(self.training or force)
         self.iteration += 1
-        if self.training or force:
-            return z, {'z': z, 'discrete': params}
-        return z_hard, {'z': z, 'discrete': params}
+        if not soft:
+            z, z_hard, log_q_z = self.reparmeterize(logits, noise=noise)
+            params = {'z_hard': z_hard, 'logits': logits, 'log_q_z': log_q_z, 'tau_scalar': self.tau}
+            return z_hard, {'z': z, 'discrete': params}
+        # training: the step reads the soft sample only, so the launch writes nothing else; z_hard and log_q_z keep
+        # their places in the params dict and are produced on first read (12K bytes per sample instead of 20K)
+        z, _, _ = self.reparmeterize(logits, noise=noise, want=(True, False, False))
+        params = LazyParams()
+        params.set_lazy('z_hard', lambda: hard_from_soft_max(z))
+        params['logits'] = logits
+        params.set_lazy('log_q_z', lambda: F_.log_softmax_rows(logits))
+        params['tau_scalar'] = self.tau
+        return z, {'z': z, 'discrete': params}
