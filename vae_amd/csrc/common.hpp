@@ -345,8 +345,10 @@ struct Philox {
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-      uint32_t hi0 = __umulhi(kM0, c0), lo0 = kM0 * c0;
-      uint32_t hi1 = __umulhi(kM1, c2), lo1 = kM1 * c2;
+      // one 32x32->64 product each (v_mad_u64_u32) instead of a mul_hi + mul_lo pair
+      const uint64_t p0 = (uint64_t)kM0 * (uint64_t)c0, p1 = (uint64_t)kM1 * (uint64_t)c2;
+      const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+      const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
       uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
       c0 = n0; c1 = n1; c2 = n2; c3 = n3;
       k0 += kW0; k1 += kW1;
@@ -362,11 +364,12 @@ __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5
 __device__ __forceinline__ void normal4(const uint32_t (&w)[4], float (&n)[4]) {
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    float r = sqrtf(-2.0f * fast_log(u01(w[2 * p])));
-    float s, c;
-    __sincosf(6.283185307179586f * u01(w[2 * p + 1]), &s, &c);
-    n[2 * p] = r * c;
-    n[2 * p + 1] = r * s;
+    // r = sqrt(-2 ln u) from bare v_log_f32 / v_sqrt_f32 (u in (0,1): normal range); the angle is fed to
+    // v_sin_f32 / v_cos_f32 directly in turns (their native unit), no 2*pi multiply and no range reduction
+    const float r = __builtin_amdgcn_sqrtf(-2.0f * kLn2 * log2_raw(u01(w[2 * p])));
+    const float t = u01(w[2 * p + 1]);
+    n[2 * p] = r * __builtin_amdgcn_cosf(t);
+    n[2 * p + 1] = r * __builtin_amdgcn_sinf(t);
   }
 }
 

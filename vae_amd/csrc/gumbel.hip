@@ -90,8 +90,17 @@ __global__ __launch_bounds__(kBlock) void gumbel_fwd_kernel(
         if (!unif) philox_uniform<V>(seed, offset, (uint64_t)(row0 + r) * (uint64_t)K + (uint64_t)j * V, u[k]);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-          float g = -logf(add_rn(u[k][i], kGumbelEps));
-          g = -logf(add_rn(g, kGumbelEps));
+          // injected U: the reference's own roundings (accurate logs).  In-kernel draws have nothing to be
+          // bit-compared with and this path is ALU-bound (Philox + two logs per element): bare v_log_f32, whose
+          // arguments (>= 1e-9) are in the normal range.
+          float g;
+          if (unif) {
+            g = -logf(add_rn(u[k][i], kGumbelEps));
+            g = -logf(add_rn(g, kGumbelEps));
+          } else {
+            g = -fast_log(u[k][i] + kGumbelEps);
+            g = -fast_log(g + kGumbelEps);
+          }
           g = to_f32(from_f32<T>(g));
           const float xi = to_f32(from_f32<T>(div_rn(to_f32(from_f32<T>(add_rn(l[k][i], g))), tau)));
           x[k][i] = to_f32(from_f32<T>(add_rn(xi, kGumbelEps)));
