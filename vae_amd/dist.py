@@ -32,14 +32,24 @@ def shard_rows(global_batch, rank=None, world_size=None):
     return row0, rows
 
 
+def _sum_over_ranks_(t, group=None):
+    """In-place all-reduce(sum).  RCCL reduces device tensors where they are; a gloo group (CPU tests, several
+    ranks rehearsing on one GPU) gets the few floats through the host."""
+    if t.is_cuda and dist.get_backend(group) == 'gloo':
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 class _AllReduceSum(torch.autograd.Function):
     """sum over ranks; the gradient passes through unchanged (every rank seeds the same cotangent)."""
 
     @staticmethod
     def forward(ctx, t, group):
-        out = t.clone()
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
-        return out
+        return _sum_over_ranks_(t.clone(), group)
 
     @staticmethod
     def backward(ctx, g):
@@ -64,7 +74,7 @@ def packed_all_reduce(tensors, group=None):
 def all_reduce_inplace(t, group=None):
     """reduce_fn for functional.flow_kl: in-place sum of a small float tensor over ranks."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        _sum_over_ranks_(t, group)
     return t
 
 
