@@ -101,6 +101,17 @@ class ELBOMixin(object):
     def kld(self, dist_a):
         return self.reparameterizer.kl(dist_a)
 
+    def reparameterize_aggregate_posterior(self):
+        """abstract_vae.py:159-172: a training-mode draw from the EMA of the encoder logits that the host model keeps
+        in `self.aggregate_posterior` (helpers.layers.EMA: stock, un-vendored)."""
+        training_tmp = self.reparameterizer.training
+        self.reparameterizer.train(True)
+        ema = self.aggregate_posterior.ema_val
+        labels = torch.arange(self.config['output_size'], device=ema.device)
+        z_samples, _ = self.reparameterize(ema, labels=labels)
+        self.reparameterizer.train(training_tmp)
+        return z_samples
+
     def nll(self, x, recon_x, nll_type):
         return nll(x, recon_x, nll_type)
 
