@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""What a host model looks like once the hot path is swapped in (simple_vae.py + abstract_vae.py of the reference,
+restated with nn.Linear networks and synthetic data): the encoder / decoder are stock PyTorch, the latent and loss
+half comes from vae_amd (ELBOMixin + a reparameterizer class from the registry).
+
+    python examples/train_simple_vae.py --steps 50                       # one GPU
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 \
+        examples/train_simple_vae.py --steps 50                         # one process per GPU, RCCL
+
+Multi-GPU: every rank owns B rows of the global batch.  vae_amd.dist.configure() points the reparameterizer at
+its shard (global row offset for the in-kernel Philox draws, 1/B_global scaling of the batch means);
+globalize_loss() is the one packed all-reduce of the loss scalars; DDP averages the network gradients, so the
+loss that is backpropagated is multiplied by world_size (the kernels already divide by B_global)."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+import torch.nn as nn
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vae_amd  # noqa: E402
+from vae_amd import dist as vdist  # noqa: E402
+from vae_amd.elbo import ELBOMixin  # noqa: E402
+
+
+class SimpleVAE(ELBOMixin, nn.Module):
+    def __init__(self, config):
+        nn.Module.__init__(self)
+        self.config = config
+        self.reparameterizer = vae_amd.get_reparameterizer(config['reparam_type'])(config)
+        d_in = 28 * 28
+        self.encoder = nn.Sequential(nn.Linear(d_in, 512), nn.ReLU(), nn.Linear(512, self.reparameterizer.input_size))
+        self.decoder = nn.Sequential(nn.Linear(self.reparameterizer.output_size, 512), nn.ReLU(), nn.Linear(512, d_in))
+
+    def forward(self, x):
+        z, params = self.reparameterize(self.encoder(x.flatten(1)))
+        return self.decoder(z).view_as(x), params
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--batch', type=int, default=4096, help='rows per GPU')
+    ap.add_argument('--latent', type=int, default=64)
+    args = ap.parse_args()
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
+    torch.cuda.set_device(dev)
+    if world > 1:
+        torch.distributed.init_process_group('nccl', device_id=dev)
+    config = {'reparam_type': 'isotropic_gaussian', 'continuous_size': 2 * args.latent, 'nll_type': 'bernoulli',
+              'kl_beta': 1.0, 'cuda': True, 'half': False, 'continuous_mut_info': 0, 'discrete_mut_info': 0}
+    torch.manual_seed(0)
+    model = SimpleVAE(config).to(dev).train()
+    net = model
+    if world > 1:
+        vdist.configure(model, args.batch * world)
+        net = nn.parallel.DistributedDataParallel(model, device_ids=[dev.index])
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+    proto = (torch.rand(16, 1, 28, 28, generator=gen, device=dev) < 0.15).float()      # 16 "digit" prototypes
+    t0 = time.perf_counter()
+    for step in range(args.steps):
+        idx = torch.randint(0, 16, (args.batch,), generator=gen, device=dev)
+        flip = (torch.rand(args.batch, 1, 28, 28, generator=gen, device=dev) < 0.02).float()
+        x = (proto[idx] + flip).remainder(2)
+        recon, params = net(x)
+        loss = model.loss_function(recon, x, params)
+        if world > 1:
+            loss, _ = vdist.globalize_loss(loss)
+        opt.zero_grad(set_to_none=True)
+        (loss['loss_mean'] * world).backward()
+        opt.step()
+        if rank == 0 and (step % 10 == 0 or step == args.steps - 1):
+            print('step %4d  loss %.3f  nll %.3f  kld %.3f' % (step, float(loss['loss_mean']), float(loss['nll_mean']),
+                                                              float(loss['kld_mean'])), flush=True)
+    torch.cuda.synchronize()
+    if rank == 0:
+        dt = time.perf_counter() - t0
+        print('%d steps, %.0f samples/s (whole model, %d GPU%s)' % (args.steps, args.steps * args.batch * world / dt,
+                                                                    world, 's' if world > 1 else ''))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
