@@ -288,6 +288,13 @@ def main():
         module_path = {'ms_per_step': round(mms, 4), 'samples_per_s': B / (mms * 1e-3),
                        'what': 'IsotropicGaussian.forward + .kl + elbo.loss_function + autograd backward, 20 steps'}
 
+    # the reference's own op sequence for this step in stock PyTorch-ROCm on this GPU (isotropic_gaussian.py:77-131,
+    # 158-170 through torch.distributions; abstract_vae.py:356-387; Bernoulli-with-logits NLL), same resident inputs
+    # and injected noise: what the reference does on an MI355X without this library.  Reported beside the figure.
+    stock_torch = None
+    if world == 1 and not args.main_only:
+        stock_torch = stock_torch_step_rate(logits, noise, x.view(B, C, H, W), recon.view(B, C, H, W), gz)
+
     if rank == 0:
         ab = algorithmic_bytes(B, philox)
         kernels = {}
@@ -335,6 +342,7 @@ def main():
             'loss_mean': sanity,
             'module_path': module_path,
             'philox_variant': philox_variant,
+            'stock_torch_same_gpu': stock_torch,
         }
         if world == 1 and not args.no_cpu_baseline and not args.main_only:
             out['cpu_baseline'] = cpu_baseline()
@@ -342,6 +350,41 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def stock_torch_step_rate(logits, noise, x, recon, gz, steps=10):
+    import torch
+    import torch.distributions as D
+    import torch.nn.functional as F
+    D.Distribution.set_default_validate_args(False)
+    B, L2 = logits.shape
+    lg = logits.detach().requires_grad_(True)
+    rc = recon.detach().requires_grad_(True)
+
+    def one():
+        mu, s = lg[:, :L2 // 2], lg[:, L2 // 2:] + 1e-6
+        z = noise * (0.5 * s) + mu
+        mu_mean, logvar_mean = mu.mean(), s.mean()
+        kld = D.kl_divergence(D.Normal(mu, s), D.Normal(torch.zeros_like(mu), torch.ones_like(s))).sum(-1)
+        nll = F.binary_cross_entropy_with_logits(rc, x, reduction='none').view(B, -1).sum(-1)
+        elbo, loss = nll + kld, nll + 1.0 * kld
+        out = (loss.mean(), elbo.mean(), nll.mean(), kld.mean(), mu_mean, logvar_mean)
+        torch.autograd.backward([out[0], z], [None, gz])
+        lg.grad = None
+        rc.grad = None
+        return out
+    for _ in range(3):
+        one()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        one()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    return {'ms_per_step': round(ms, 4), 'samples_per_s': B / (ms * 1e-3),
+            'what': 'unfused torch ops + torch.distributions KL + BCE-with-logits + autograd, %d steps' % steps}
 
 
 def ctypes_off(t, n):
