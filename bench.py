@@ -9,8 +9,8 @@ per GPU, 1x28x28 Bernoulli NLL, fp32, synthetic inputs resident in HBM.  One ste
 the hot path over one batch, forward and backward:
 
     gauss_reparam_kl_fwd -> nll_elbo_fused (forward AND d loss_mean / d recon in one read of x, recon)
-    -> [N>1: one packed all-reduce of the 8 batch scalars] -> nll_fused_grad_finish (device-side rescale,
-    a no-op for loss_mean.backward()'s unit gradient) + elbo_combine_bwd ([B]: d kld) -> gauss_reparam_kl_bwd
+    -> [N>1: one packed all-reduce of the 8 batch scalars] -> nll_fused_backward (one launch: device-side
+    rescale, a no-op for loss_mean.backward()'s unit gradient, and d kld [B]) -> gauss_reparam_kl_bwd
 
 (`--two-pass` times the reference-shaped sequence instead: nll_elbo_fwd ... nll_elbo_bwd, which reads x and
 recon twice; both produce the same outputs and gradients.)
@@ -48,7 +48,7 @@ def algorithmic_bytes(B, philox=False):
         'nll_elbo_fwd': (8 * D + 12) * B,           # x 4D + recon 4D + kld 4 + loss, elbo 8
         'nll_elbo_bwd': (12 * D) * B,               # x 4D + recon 4D + grecon 4D
         'nll_elbo_fused': (12 * D + 12) * B,        # x 4D + recon 4D + grecon 4D + kld 4 + loss, elbo 8
-        'grad_finish': 12 * B,                      # gmeans -> d kld [B] (+ the skipped rescale): latency only
+        'nll_fused_backward': 4 * B,                # gmeans -> d kld [B] (+ the skipped rescale): latency only
     }
 
 
@@ -159,7 +159,7 @@ def main():
     philox = args.noise == 'philox'
     plogvar = ptr(logvar) if args.materialize_logvar else None
     noise_arg = [None if philox else ptr(noise)]   # None: the kernels draw Philox noise themselves
-    names = ['gauss_reparam_kl_fwd', 'nll_elbo_fused', 'grad_finish', 'gauss_reparam_kl_bwd'] if fused else \
+    names = ['gauss_reparam_kl_fwd', 'nll_elbo_fused', 'nll_fused_backward', 'gauss_reparam_kl_bwd'] if fused else \
         ['gauss_reparam_kl_fwd', 'nll_elbo_fwd', 'nll_elbo_bwd', 'gauss_reparam_kl_bwd']
     pmeans = ctypes_off(scalars, 6)
 
@@ -192,8 +192,8 @@ def main():
                 all_reduce(scalars)
         mark(3)
         if fused:
-            call('vae_nll_fused_grad_finish', ptr(grecon), ptr(gmeans), B * D, 0, st)
-            call('vae_elbo_combine_bwd', None, None, ptr(gmeans), 1.0, inv_count, None, ptr(gkld), None, None, B, 0, st)
+            call('vae_nll_fused_backward', ptr(grecon), B * D, ptr(gmeans), 1.0, inv_count, ptr(gkld), None, None, B,
+                 0, st)
         else:
             call('vae_nll_elbo_bwd', ptr(x), ptr(recon), 0, None, None, None, ptr(gmeans), 1.0, inv_count,
                  ptr(grecon), ptr(gkld), None, None, B, D, 0, st)

@@ -223,6 +223,12 @@ int vae_nll_elbo_fused(const void* x, const void* recon, int nll_type, const voi
                        float kl_beta, float inv_count, float grad_scale, void* nll, void* loss, void* elbo, float* means,
                        float* workspace, void* grecon, int64_t B, int64_t D, int dtype, vae_stream_t stream);
 int vae_nll_fused_grad_finish(void* grecon, const float* gmeans, int64_t n, int dtype, vae_stream_t stream);
+/* Both of the above in one launch, for the step whose only upstream gradients are those of the six means
+ * (loss['loss_mean'].backward(), abstract_vae.py:381): the conditional rescale of the n stored gradient values
+ * and gkld / gadd / gmi [B] (each may be NULL) = what vae_elbo_combine_bwd writes with gloss = gelbo = NULL.
+ * gmeans: device array of 6 floats.  No counterpart in the reference (its autograd runs ~10 launches here). */
+int vae_nll_fused_backward(void* grecon, int64_t n, const float* gmeans, float kl_beta, float inv_count, void* gkld,
+                           void* gadd, void* gmi, int64_t B, int dtype, vae_stream_t stream);
 /* The ELBO combine alone, from a given nll [B] (K > 1 Monte-Carlo average,
  * abstract_vae.py:347-354; VRNN per-step dicts, vrnn.py:823-829).               */
 int vae_elbo_combine_fwd(const void* nll, const void* kld, const void* add, const void* mi, float kl_beta,

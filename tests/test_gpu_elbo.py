@@ -242,6 +242,38 @@ def test_fused_backward_matches_two_pass_and_oracle(nll_type, shape, upstream):
         close(gw, gw0, rtol=1e-5, atol=2e-7 * float(gw0.abs().max()))
 
 
+@pytest.mark.parametrize('B,D', [(1, 1), (7, 3), (300, 784), (4096, 100), (3, 4099)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('gm', [(1.0, 0, 0, 0, 0, 0), (0.5, 0.25, 0.25, 0, 0, 0), (2.0, 1.0, -0.5, 3.0, 0.7, -1.5)])
+def test_fused_backward_one_launch_equals_finish_plus_combine(B, D, dtype, gm):
+    """vae_nll_fused_backward == vae_nll_fused_grad_finish + vae_elbo_combine_bwd (the rescaled gradient bit for
+    bit; the per-row constants to an ulp: the two kernels contract beta * g + g' differently)."""
+    from vae_amd import _lib
+    from vae_amd._lib import call, ptr
+    code = 0 if dtype == torch.float32 else 1
+    st = _lib.stream_ptr(torch.device(DEV))
+    torch.manual_seed(B + D)
+    g = torch.randn(B, D).to(dtype).to(DEV)
+    gmeans = torch.tensor(gm, dtype=torch.float32, device=DEV)
+    a, b = g.clone(), g.clone()
+    outs_a = [torch.full((B,), 7.0, dtype=dtype, device=DEV) for _ in range(3)]
+    outs_b = [torch.full((B,), 9.0, dtype=dtype, device=DEV) for _ in range(3)]
+    call('vae_nll_fused_grad_finish', ptr(a), ptr(gmeans), B * D, code, st)
+    call('vae_elbo_combine_bwd', None, None, ptr(gmeans), 0.3, 1.0 / B, None, ptr(outs_a[0]), ptr(outs_a[1]),
+         ptr(outs_a[2]), B, code, st)
+    call('vae_nll_fused_backward', ptr(b), B * D, ptr(gmeans), 0.3, 1.0 / B, ptr(outs_b[0]), ptr(outs_b[1]),
+         ptr(outs_b[2]), B, code, st)
+    assert torch.equal(a, b)
+    if gm[0] + gm[1] + gm[2] == 1.0:
+        assert torch.equal(b, g)                      # unit upstream gradient: untouched
+    for u, v in zip(outs_a, outs_b):
+        close(v, u, rtol=1e-6 if dtype == torch.float32 else 1e-2, atol=0)
+    # NULL outputs are skipped
+    keep = torch.full((B,), 5.0, dtype=dtype, device=DEV)
+    call('vae_nll_fused_backward', ptr(b), B * D, ptr(gmeans), 0.3, 1.0 / B, None, ptr(keep), None, B, code, st)
+    close(keep, outs_a[1], rtol=1e-6 if dtype == torch.float32 else 1e-2, atol=0)
+
+
 def test_fused_backward_bf16_and_no_grad():
     from vae_amd import elbo as E
     torch.manual_seed(4)

@@ -298,6 +298,36 @@ __global__ __launch_bounds__(kBlock) void scale_by_mean_grads_kernel(T* __restri
   }
 }
 
+// The whole backward of a one-pass step whose upstream gradients are the six mean gradients only, in ONE launch:
+// the [B]-sized d kld / d add / d mi (constants per row: elbo_combine_bwd with no per-sample upstream) and the
+// conditional rescale of the stored d recon.
+template <typename T, int V>
+__global__ __launch_bounds__(kBlock) void nll_fused_backward_kernel(T* __restrict__ buf, const float* __restrict__ gmeans,
+                                                                    int64_t nvec_total, T* __restrict__ gkld,
+                                                                    T* __restrict__ gadd, T* __restrict__ gmi, int64_t B,
+                                                                    float kl_beta, float inv_count) {
+  float gm[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) gm[k] = gmeans[k] * inv_count;
+  const T vk = from_f32<T>(kl_beta * gm[0] + gm[1] + gm[3]);
+  const T va = from_f32<T>(gm[0] + gm[4]);
+  const T vm = from_f32<T>(gm[5] - gm[0]);
+  for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < B; row += (int64_t)gridDim.x * kBlock) {
+    if (gkld) gkld[row] = vk;
+    if (gadd) gadd[row] = va;
+    if (gmi) gmi[row] = vm;
+  }
+  const float c = gmeans[0] + gmeans[1] + gmeans[2];
+  if (c == 1.0f) return;
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < nvec_total; j += (int64_t)gridDim.x * kBlock) {
+    float v[V];
+    load_vec<T, V, false>(buf + j * V, v);
+#pragma unroll
+    for (int i = 0; i < V; ++i) v[i] *= c;
+    store_vec<T, V>(buf + j * V, v);
+  }
+}
+
 template <typename T, int NLL>
 static int nll_fused_dispatch(const void* x, const void* recon, const void* kld, const void* add, const void* mi,
                               void* nll, void* loss, void* elbo, float* means, float* workspace, void* grecon,
@@ -490,6 +520,29 @@ int vae_nll_fused_grad_finish(void* grecon, const float* gmeans, int64_t n, int 
   } else {
     if (vec) hipLaunchKernelGGL((scale_by_mean_grads_kernel<bf16_t, 8>), dim3(grid), dim3(kBlock), 0, st, (bf16_t*)grecon, gmeans, items);
     else hipLaunchKernelGGL((scale_by_mean_grads_kernel<bf16_t, 1>), dim3(grid), dim3(kBlock), 0, st, (bf16_t*)grecon, gmeans, items);
+  }
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+int vae_nll_fused_backward(void* grecon, int64_t n, const float* gmeans, float kl_beta, float inv_count, void* gkld,
+                           void* gadd, void* gmi, int64_t B, int dtype, vae_stream_t stream) {
+  if (n < 0 || B < 0 || (dtype != VAE_F32 && dtype != VAE_BF16)) return VAE_ERR_ARG;
+  if (n == 0 && B == 0) return VAE_OK;
+  if (!gmeans || (n > 0 && !grecon)) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int VN = dtype == VAE_F32 ? 4 : 8;
+  const bool vec = (n % VN == 0) && aligned16(grecon);
+  const int64_t items = vec ? n / VN : n;
+  // sized for the [B] part; the (rare) rescale walks the gradient with the same grid
+  int64_t blocks = (B + kBlock - 1) / kBlock;
+  if (blocks < 1024 && items > B) blocks = (items + kBlock - 1) / kBlock < 1024 ? (items + kBlock - 1) / kBlock : 1024;
+  const int grid = (int)(blocks < 4096 ? (blocks < 1 ? 1 : blocks) : 4096);
+  if (dtype == VAE_F32) {
+    if (vec) hipLaunchKernelGGL((nll_fused_backward_kernel<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)grecon, gmeans, items, (float*)gkld, (float*)gadd, (float*)gmi, B, kl_beta, inv_count);
+    else hipLaunchKernelGGL((nll_fused_backward_kernel<float, 1>), dim3(grid), dim3(kBlock), 0, st, (float*)grecon, gmeans, items, (float*)gkld, (float*)gadd, (float*)gmi, B, kl_beta, inv_count);
+  } else {
+    if (vec) hipLaunchKernelGGL((nll_fused_backward_kernel<bf16_t, 8>), dim3(grid), dim3(kBlock), 0, st, (bf16_t*)grecon, gmeans, items, (bf16_t*)gkld, (bf16_t*)gadd, (bf16_t*)gmi, B, kl_beta, inv_count);
+    else hipLaunchKernelGGL((nll_fused_backward_kernel<bf16_t, 1>), dim3(grid), dim3(kBlock), 0, st, (bf16_t*)grecon, gmeans, items, (bf16_t*)gkld, (bf16_t*)gadd, (bf16_t*)gmi, B, kl_beta, inv_count);
   }
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }

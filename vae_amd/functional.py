@@ -247,11 +247,8 @@ class _NllElboFused(torch.autograd.Function):
         ctx.grecon = None
         with _Guard(dev):
             if gnll is None and gloss is None and gelbo is None and gmeans is not None and grecon is not None:
-                call('vae_nll_fused_grad_finish', ptr(grecon), ptr(gmeans), grecon.numel(), dtype_code(x),
-                     stream_ptr(dev))
-                if gkld is not None or gadd is not None or gmi is not None:
-                    call('vae_elbo_combine_bwd', None, None, ptr(gmeans), kl_beta, inv_count, None, ptr(gkld),
-                         ptr(gadd), ptr(gmi), B, dtype_code(x), stream_ptr(dev))
+                call('vae_nll_fused_backward', ptr(grecon), grecon.numel(), ptr(gmeans), kl_beta, inv_count,
+                     ptr(gkld), ptr(gadd), ptr(gmi), B, dtype_code(x), stream_ptr(dev))
             else:
                 grecon = torch.empty_like(recon)
                 call('vae_nll_elbo_bwd', ptr(x), ptr(recon), nll_code, ptr(gnll), ptr(gloss), ptr(gelbo), ptr(gmeans),
