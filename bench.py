@@ -305,7 +305,7 @@ def main():
         dom = max(names, key=lambda n: dur_ms[n])
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and B == B_PER_GPU:   # the PMC passes were collected at the default batch
             # profiles/traffic.json: PMC bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, scripts/summarize_pmc.py),
             # keyed by bench kernel name or by the full kernel symbol with a short 'kernel' field
             short = {'gauss_reparam_kl_fwd': 'gauss_fwd_kernel', 'gauss_reparam_kl_bwd': 'gauss_bwd_kernel',
