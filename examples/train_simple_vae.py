@@ -46,10 +46,15 @@ def main():
     ap.add_argument('--latent', type=int, default=64)
     args = ap.parse_args()
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
-    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
+    # EXAMPLE_BACKEND=gloo lets several ranks share one GPU (a rehearsal of the wiring on a one-GPU box)
+    backend = os.environ.get('EXAMPLE_BACKEND', 'nccl')
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)) % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     if world > 1:
-        torch.distributed.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            torch.distributed.init_process_group('nccl', device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
     config = {'reparam_type': 'isotropic_gaussian', 'continuous_size': 2 * args.latent, 'nll_type': 'bernoulli',
               'kl_beta': 1.0, 'cuda': True, 'half': False, 'continuous_mut_info': 0, 'discrete_mut_info': 0}
     torch.manual_seed(0)
