@@ -178,3 +178,39 @@ def test_c5_vrnn_step_16384x128():
     assert torch.equal(zq.cpu(), z0['posterior'])
     close(zp, z0['prior'], rtol=1e-6, atol=1e-6)     # sigmoid in the clamp: 1-ulp forms differ
     close(klpair + klprior, kl0, rtol=1e-5, atol=1e-5 * L)
+
+
+def test_beyond_int32_elements():
+    """Tensors with more than 2^31 elements (64-bit row offsets everywhere): the last rows of a 9-10 GB launch equal
+    the same rows computed alone, forward and backward, for the Gaussian pair of kernels and the one-pass NLL."""
+    from vae_amd import functional as F_
+    gd = torch.Generator(device=DEV).manual_seed(21)
+    # Gaussian: B * 2L = 2.25e9 elements of logits
+    B, L = 2_200_000, 512
+    logits = torch.randn(B, 2 * L, generator=gd, device=DEV).requires_grad_(True)
+    noise = torch.randn(B, L, generator=gd, device=DEV)
+    assert logits.numel() > 2 ** 31
+    z, _, kl, _ = F_.gauss_reparam_kl(logits, noise)
+    (g,) = torch.autograd.grad(z.sum() + kl.sum(), logits)
+    tail = logits[-1000:].detach().clone().requires_grad_(True)
+    zt, _, klt, _ = F_.gauss_reparam_kl(tail, noise[-1000:].clone())
+    (gt,) = torch.autograd.grad(zt.sum() + klt.sum(), tail)
+    assert torch.equal(z[-1000:], zt) and torch.equal(kl[-1000:], klt) and torch.equal(g[-1000:], gt)
+    assert bool(torch.isfinite(kl).all())
+    del logits, noise, z, kl, g
+    torch.cuda.empty_cache()
+    # Gaussian NLL on 3x64x64 images: recon has B * 24576 = 2.4e9 elements
+    Bn = 98_304
+    x = torch.rand(Bn, 3, 64, 64, generator=gd, device=DEV)
+    recon = torch.randn(Bn, 6, 64, 64, generator=gd, device=DEV).requires_grad_(True)
+    assert recon.numel() > 2 ** 31
+    kld = torch.rand(Bn, generator=gd, device=DEV)
+    n, l, e, means = F_.nll_elbo(x, recon, 'gaussian', kld=kld, fuse_backward=True)
+    (gr,) = torch.autograd.grad(means[0], recon)
+    rt = recon[-64:].detach().clone().requires_grad_(True)
+    nt, lt, et, mt = F_.nll_elbo(x[-64:].clone(), rt, 'gaussian', kld=kld[-64:].clone(), inv_count=1.0 / Bn,
+                                 fuse_backward=True)
+    (grt,) = torch.autograd.grad(mt[0], rt)
+    assert torch.equal(n[-64:], nt) and torch.equal(l[-64:], lt)
+    assert torch.equal(gr[-64:], grt)
+    close(means[2], n.double().mean().float(), rtol=1e-6, atol=0)
