@@ -157,8 +157,10 @@ __global__ __launch_bounds__(kBlock) void coupling_tail_fwd_kernel(
 #pragma unroll
             for (int i = 0; i < V; ++i) {
               const float inv = 1.0f - mk[k][i];
-              const float ls = s_raw ? sv[k][i] * inv : 0.f;
-              o[i] = xv[k][i] * (s_raw ? expf(ls) : 1.0f) + tv[k][i] * inv;
+              const float ls = s_raw ? mul_rn(sv[k][i], inv) : 0.f;
+              // separate roundings, as the reference's x * exp(log_s) + t (flows/__init__.py:524-528): no FMA
+              // contraction, so the vector and scalar instantiations agree bit for bit
+              o[i] = add_rn(s_raw ? mul_rn(xv[k][i], expf(ls)) : xv[k][i], mul_rn(tv[k][i], inv));
               s += ls;
             }
             store_vec<T, V>(y + row * F + (int64_t)j * V, o);
