@@ -1,6 +1,8 @@
 """The example host model (examples/train_simple_vae.py) trains: the loss after 40 steps is well below the first."""
 import os
 import re
+import signal
+import socket
 import subprocess
 import sys
 
@@ -10,22 +12,42 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _run(cmd, env=None, timeout=100):
+    """Run in its own process group; a run that does not finish is killed as a group (no stray ranks left on the GPU)
+    and reported, never waited on."""
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env,
+                         start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        pytest.fail('timed out after %d s: %s\n%s' % (timeout, ' '.join(cmd), err[-2000:]))
+    return p.returncode, out, err
+
+
+def _check_losses(rc, out, err):
+    assert rc == 0, err[-3000:]
+    losses = [float(m) for m in re.findall(r'loss ([0-9.]+)', out)]
+    assert len(losses) >= 4 and losses[-1] < 0.7 * losses[0], out
+
+
 def test_example_trains():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'examples', 'train_simple_vae.py'), '--steps', '41',
-                          '--batch', '1024'], capture_output=True, text=True, timeout=300, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
-    losses = [float(m) for m in re.findall(r'loss ([0-9.]+)', out.stdout)]
-    assert len(losses) >= 4 and losses[-1] < 0.7 * losses[0], out.stdout
+    _check_losses(*_run([sys.executable, os.path.join(ROOT, 'examples', 'train_simple_vae.py'), '--steps', '41',
+                         '--batch', '1024']))
 
 
 def test_example_trains_two_ranks_gloo():
     """The DDP wiring of the example (vae_amd.dist.configure + globalize_loss + DistributedDataParallel) with two
     ranks sharing the GPU over gloo: the global-batch loss falls."""
     env = dict(os.environ, EXAMPLE_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                          '--master-addr', '127.0.0.1', '--master-port', '29533',
-                          os.path.join(ROOT, 'examples', 'train_simple_vae.py'), '--steps', '41', '--batch', '512'],
-                         capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
-    losses = [float(m) for m in re.findall(r'loss ([0-9.]+)', out.stdout)]
-    assert len(losses) >= 4 and losses[-1] < 0.7 * losses[0], out.stdout
+    _check_losses(*_run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                         '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+                         os.path.join(ROOT, 'examples', 'train_simple_vae.py'), '--steps', '41', '--batch', '512'],
+                        env=env))

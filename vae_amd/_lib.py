@@ -130,8 +130,19 @@ def ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def _stream_handle(device):
+    """The current HIP stream of `device` as an integer (the raw accessor skips building a Stream object: ~8 us
+    per call on the module path, which launches 30-40 us kernels)."""
+    if _raw_stream is not None:
+        return _raw_stream(device.index if device.index is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def stream_ptr(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return ctypes.c_void_p(_stream_handle(device))
 
 
 _workspaces = {}
@@ -139,7 +150,7 @@ _workspaces = {}
 
 def workspace(device):
     """Per (device, stream) scratch for block partials; one call at a time per stream."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _stream_handle(device))
     ws = _workspaces.get(key)
     if ws is None:
         nbytes = load().vae_workspace_bytes()

@@ -26,6 +26,14 @@ def _dense(t):
     return None if t is None else t.contiguous()
 
 
+def _scalars(n, dev, B):
+    """fp32[n] for a kernel's batch scalars.  Every launch with B > 0 writes all n of them (the closing block of the
+    grid-wide sum), so no fill kernel is spent on them; a B == 0 call is a no-op and gets zeros."""
+    if B > 0:
+        return torch.empty((n,), dtype=torch.float32, device=dev)
+    return torch.zeros((n,), dtype=torch.float32, device=dev)
+
+
 class _Guard(object):
     """Make the tensors' device current for the launch when it is not already."""
 
@@ -53,7 +61,7 @@ class _GaussReparamKL(torch.autograd.Function):
         z = torch.empty((B, L), dtype=logits.dtype, device=dev) if training else None
         logvar = torch.empty((B, L), dtype=logits.dtype, device=dev) if want_logvar else None
         kl = torch.empty((B,), dtype=logits.dtype, device=dev)
-        means = torch.zeros((2,), dtype=torch.float32, device=dev)
+        means = _scalars(2, dev, B)
         if mean_scale is None:
             mean_scale = 1.0 / max(B * L, 1)
         with _Guard(dev):
@@ -170,7 +178,7 @@ class _NllElbo(torch.autograd.Function):
         if with_elbo:
             loss = torch.empty_like(nll)
             elbo = torch.empty_like(nll)
-            means = torch.zeros((6,), dtype=torch.float32, device=dev)
+            means = _scalars(6, dev, B)
             ws = workspace(dev)
         else:
             loss = elbo = means = ws = None
@@ -220,7 +228,7 @@ class _NllElboFused(torch.autograd.Function):
         B, D = x.shape
         nll = torch.empty((B,), dtype=x.dtype, device=dev)
         loss, elbo = torch.empty_like(nll), torch.empty_like(nll)
-        means = torch.zeros((6,), dtype=torch.float32, device=dev)
+        means = _scalars(6, dev, B)
         grecon = torch.empty_like(recon)
         with _Guard(dev):
             call('vae_nll_elbo_fused', ptr(x), ptr(recon), nll_code, ptr(kld), ptr(add), ptr(mi), kl_beta, inv_count,
@@ -298,7 +306,7 @@ class _ElboCombine(torch.autograd.Function):
         B = nll_.shape[0]
         loss = torch.empty_like(nll_)
         elbo = torch.empty_like(nll_)
-        means = torch.zeros((6,), dtype=torch.float32, device=dev)
+        means = _scalars(6, dev, B)
         with _Guard(dev):
             call('vae_elbo_combine_fwd', ptr(nll_), ptr(kld), ptr(add), ptr(mi), kl_beta, inv_count, ptr(loss),
                  ptr(elbo), ptr(means), ptr(workspace(dev)), B, dtype_code(nll_), stream_ptr(dev))
@@ -526,7 +534,7 @@ class _BetaSplitKL(torch.autograd.Function):
         c1 = torch.empty((B, L), dtype=logits.dtype, device=dev)
         c0 = torch.empty_like(c1)
         kl = torch.empty((B,), dtype=logits.dtype, device=dev)
-        means = torch.zeros((2,), dtype=torch.float32, device=dev)
+        means = _scalars(2, dev, B)
         if mean_scale is None:
             mean_scale = 1.0 / max(B * L, 1)
         with _Guard(dev):
@@ -677,7 +685,7 @@ class _GaussPair(torch.autograd.Function):
         z_p = new(B, L) if training else None
         lv_q, lv_p, clamped, kl_pair = new(B, L), new(B, L), new(B, 2 * L), new(B)
         kl_prior = new(B) if with_prior_kl else None
-        means = torch.zeros((4,), dtype=torch.float32, device=dev)
+        means = _scalars(4, dev, B)
         if mean_scale is None:
             mean_scale = 1.0 / max(B * L, 1)
         with _Guard(dev):
@@ -766,7 +774,7 @@ class _ConcatLeaves(torch.autograd.Function):
                 if kind == 'gauss':
                     _, L, eps_tol, mean_scale = spec
                     logvar, kl = logits.new_empty((0,)), new(B)   # logvar is produced lazily by the module class
-                    means = torch.zeros((2,), dtype=torch.float32, device=dev)
+                    means = _scalars(2, dev, B)
                     ms = 1.0 / max(B * L, 1) if mean_scale is None else mean_scale
                     call('vae_gauss_reparam_kl_fwd', _poff(logits, i_off), rs, ptr(noise), _poff(zcat, o_off), W_out,
                          None, ptr(kl), ptr(means), ptr(workspace(dev)), B, L, eps_tol, ms, int(training),
@@ -877,7 +885,7 @@ class _GaussMulti(torch.autograd.Function):
         z = torch.empty((S, B, L), dtype=logits.dtype, device=dev)
         logvar = torch.empty((B, L), dtype=logits.dtype, device=dev) if want_logvar else None
         kl = torch.empty((B,), dtype=logits.dtype, device=dev)
-        means = torch.zeros((2,), dtype=torch.float32, device=dev)
+        means = _scalars(2, dev, B)
         if mean_scale is None:
             mean_scale = 1.0 / max(B * L, 1)
         with _Guard(dev):
@@ -936,7 +944,7 @@ class _NllMultiElbo(torch.autograd.Function):
         nll = torch.empty((B,), dtype=x.dtype, device=dev)
         if with_elbo:
             loss, elbo = torch.empty_like(nll), torch.empty_like(nll)
-            means = torch.zeros((6,), dtype=torch.float32, device=dev)
+            means = _scalars(6, dev, B)
             ws = workspace(dev)
         else:
             loss = elbo = means = ws = None
