@@ -7,7 +7,8 @@ half comes from vae_amd (ELBOMixin + a reparameterizer class from the registry).
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 \
         examples/train_simple_vae.py --steps 50                         # one process per GPU, RCCL
 
-Multi-GPU: every rank owns B rows of the global batch.  vae_amd.dist.configure() points the reparameterizer at
+Multi-GPU: every rank owns B rows of the global batch (EXAMPLE_BACKEND=gloo rehearses the same wiring with several
+ranks on one GPU, summing gradients through vae_amd.dist instead of DDP).  vae_amd.dist.configure() points the reparameterizer at
 its shard (global row offset for the in-kernel Philox draws, 1/B_global scaling of the batch means);
 globalize_loss() is the one packed all-reduce of the loss scalars; DDP averages the network gradients, so the
 loss that is backpropagated is multiplied by world_size (the kernels already divide by B_global)."""
@@ -40,6 +41,9 @@ class SimpleVAE(ELBOMixin, nn.Module):
 
 
 def main():
+    if os.environ.get('EXAMPLE_DEBUG'):      # where is every thread if a run stalls?
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['EXAMPLE_DEBUG']), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--batch', type=int, default=4096, help='rows per GPU')
@@ -60,8 +64,10 @@ def main():
     torch.manual_seed(0)
     model = SimpleVAE(config).to(dev).train()
     net = model
+    ddp = world > 1 and backend == 'nccl'
     if world > 1:
         vdist.configure(model, args.batch * world)
+    if ddp:
         net = nn.parallel.DistributedDataParallel(model, device_ids=[dev.index])
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
@@ -76,7 +82,19 @@ def main():
         if world > 1:
             loss, _ = vdist.globalize_loss(loss)
         opt.zero_grad(set_to_none=True)
-        (loss['loss_mean'] * world).backward()
+        if ddp:      # DDP averages the per-rank gradients; they have to SUM to the global-batch gradient
+            (loss['loss_mean'] * world).backward()
+        else:
+            loss['loss_mean'].backward()
+            if world > 1:
+                # rehearsal backend: sum the per-rank gradients as one flat message through vae_amd.dist, which stages
+                # gloo traffic through the host (DDP's gloo reduction of device tensors stalls when ranks share a GPU)
+                grads = [p.grad for p in model.parameters()]
+                flat = vdist.all_reduce_inplace(torch.cat([g_.reshape(-1) for g_ in grads]))
+                o = 0
+                for g_ in grads:
+                    g_.copy_(flat[o:o + g_.numel()].view_as(g_))
+                    o += g_.numel()
         opt.step()
         if rank == 0 and (step % 10 == 0 or step == args.steps - 1):
             print('step %4d  loss %.3f  nll %.3f  kld %.3f' % (step, float(loss['loss_mean']), float(loss['nll_mean']),

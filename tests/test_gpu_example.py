@@ -44,8 +44,9 @@ def test_example_trains():
 
 
 def test_example_trains_two_ranks_gloo():
-    """The DDP wiring of the example (vae_amd.dist.configure + globalize_loss + DistributedDataParallel) with two
-    ranks sharing the GPU over gloo: the global-batch loss falls."""
+    """The multi-rank wiring of the example (vae_amd.dist.configure + globalize_loss + summed gradients) with two
+    ranks sharing the GPU over gloo: the global-batch loss falls.  (DDP itself needs one GPU per rank over RCCL;
+    its gloo reduction of device tensors stalled intermittently with both ranks on one GPU.)"""
     env = dict(os.environ, EXAMPLE_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     _check_losses(*_run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
                          '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
