@@ -313,6 +313,18 @@ int vae_bnflow_fwd(const void* x, const float* log_gamma, const float* beta, con
 /* gy [B, F] (in y's column order), glogdet [B] or NULL -> gx [B, F]; fills stats[6F, 8F].       */
 int vae_bnflow_bwd(const void* x, const void* gy, const void* glogdet, float* stats, void* gx, int64_t B, int64_t F,
                    int training, int reverse, int dtype, vae_stream_t stream);
+/* The same backward in two steps, for statistics taken over the rows of SEVERAL ranks (the forward then ran as:
+ * vae_bnflow_fwd with y == NULL and training != 0 -- statistics of this rank's rows only, into stats[0,2F) --, the
+ * caller's reduction of the moments over ranks, vae_bnflow_fwd with training == 0 on the reduced mean / var):
+ *   _sums : stats[6F,7F) = sum_b gy, [7F,8F) = sum_b gy*x_hat, [8F] = sum_b glogdet over this rank's rows;
+ *   the caller all-reduces those 2F+1 floats in place (and keeps its local copy for d log_gamma / d beta);
+ *   _apply: gx from the reduced sums, `count` = rows over all ranks.
+ * No counterpart in the reference (BatchNormFlow there sees one device's batch); SURVEY.md 8e names the
+ * cross-rank moments as what a sharded run needs to equal the single-device one.                       */
+int vae_bnflow_bwd_sums(const void* x, const void* gy, const void* glogdet, float* stats, int64_t B, int64_t F,
+                        int reverse, int dtype, vae_stream_t stream);
+int vae_bnflow_bwd_apply(const void* x, const void* gy, float* stats, void* gx, int64_t B, int64_t F, int64_t count,
+                         int reverse, int dtype, vae_stream_t stream);
 
 #ifdef __cplusplus
 }

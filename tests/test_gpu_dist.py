@@ -101,3 +101,70 @@ def test_two_ranks_on_the_kernels_equal_one_rank(tmp_path):
             torch.testing.assert_close(v, one['means'][k], rtol=1e-6, atol=1e-5)
         torch.testing.assert_close(p['mu_mean'], one['mu_mean'], rtol=1e-5, atol=1e-7)
         torch.testing.assert_close(p['lv_mean'], one['lv_mean'], rtol=1e-5, atol=1e-7)
+
+
+# ---- BatchNormFlow with the statistics of the whole sharded batch (vae_amd.dist.configure sets the hooks) ----
+FB, FF = 203, 16
+
+
+def _run_flow(rank, world):
+    from vae_amd import dist as VD
+    from vae_amd.flows import build_maf_flow
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(FB, FF, generator=g) * 1.5 + 0.3
+    w = torch.randn(FB, FF, generator=g)
+    torch.manual_seed(3)                       # the same flow weights on every rank
+    flow = build_maf_flow(FF, 32, num_blocks=2, activation_str='tanh').to(DEV).train()
+    for m in flow.modules():                   # non-trivial affine parameters
+        if hasattr(m, 'log_gamma'):
+            with torch.no_grad():
+                m.log_gamma.copy_(torch.linspace(-0.3, 0.4, FF))
+                m.beta.copy_(torch.linspace(0.5, -0.5, FF))
+    row0, rows = VD.configure(flow, FB) if world > 1 else (0, FB)
+    sl = slice(row0, row0 + rows)
+    xi = x[sl].to(DEV).requires_grad_(True)
+    u, logdet = flow(xi)
+    ((u * w[sl].to(DEV)).sum() / FB + logdet.sum() / FB).backward()
+    cpu = lambda t: t.detach().cpu()
+    bn = [m for m in flow.modules() if hasattr(m, 'log_gamma')]
+    return {'row0': row0, 'rows': rows, 'u': cpu(u), 'logdet': cpu(logdet), 'gx': cpu(xi.grad),
+            'pgrads': [cpu(p.grad) for p in flow.parameters()],
+            'running': [cpu(m.running_mean) for m in bn] + [cpu(m.running_var) for m in bn]}
+
+
+def _flow_worker(rank, world, port, outdir):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    torch.save(_run_flow(rank, world), os.path.join(outdir, 'f%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_maf_flow_uses_whole_batch_statistics(tmp_path):
+    """A 2-block MAF (MADE + BatchNormFlow + Reverse) on a batch sharded over two ranks equals the one-rank run:
+    outputs, logdet and d x per row, running statistics, and parameter gradients summed over ranks."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=_flow_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+        if p.exitcode is None:
+            p.kill()
+        assert p.exitcode == 0
+    parts = [torch.load(os.path.join(str(tmp_path), 'f%d.pt' % r), weights_only=True) for r in range(world)]
+    one = _run_flow(0, 1)
+    close = lambda a, b, tol=2e-5: torch.testing.assert_close(a, b, rtol=tol, atol=tol * max(1.0, float(b.abs().max())))
+    for p in parts:
+        sl = slice(p['row0'], p['row0'] + p['rows'])
+        close(p['u'], one['u'][sl])
+        close(p['logdet'], one['logdet'][sl])
+        close(p['gx'], one['gx'][sl], 1e-4)
+        for a, b in zip(p['running'], one['running']):
+            close(a, b)
+    for i, b in enumerate(one['pgrads']):
+        close(parts[0]['pgrads'][i] + parts[1]['pgrads'][i], b, 1e-4)

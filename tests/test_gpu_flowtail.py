@@ -282,3 +282,27 @@ def test_flow_reparameterizer_with_kernel_backed_maf():
     close(kl, O.flow_kl({'recon_x': h, 'logdet': ld}), rtol=1e-4, atol=1e-3)
     (gx,) = torch.autograd.grad(kl.sum() + z.sum(), x)
     assert bool(torch.isfinite(gx).all())
+
+
+@pytest.mark.parametrize('B,F', [(7, 5), (300, 64), (1025, 512)])
+@pytest.mark.parametrize('reverse', [False, True])
+def test_bn_split_phases_equal_the_single_call(B, F, reverse):
+    """The cross-rank form of BatchNormFlow (statistics-only forward, reduction, apply; backward sums, reduction,
+    apply) with an identity reduction and count = B is the one-device layer."""
+    from vae_amd import functional as F_
+    torch.manual_seed(B + F)
+    x = (torch.randn(B, F) * 1.7 + 0.4).to(DEV)
+    lg, beta = (torch.randn(F) * 0.2).to(DEV), torch.randn(F).to(DEV)
+    ld_in = torch.randn(B).to(DEV)
+    w, v = torch.randn(B, F).to(DEV), torch.randn(B).to(DEV)
+    calls = []
+    res = []
+    for sync in (False, True):
+        xi, lgi, bi = x.clone().requires_grad_(True), lg.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        kw = dict(reduce_fn=lambda t: calls.append(tuple(t.shape)) or t, count=B) if sync else {}
+        y, ld, m, var = F_.bnflow(xi, lgi, bi, logdet_in=ld_in, training=True, reverse=reverse, **kw)
+        g = torch.autograd.grad((y * w).sum() + (ld * v).sum(), [xi, lgi, bi])
+        res.append((y, ld, m, var) + g)
+    assert calls == [(2 * F + 1,), (2 * F + 1,)]
+    for a, b in zip(*res):
+        torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-5 * max(1.0, float(a.abs().max())))

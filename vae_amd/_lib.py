@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the CDLL below, see module 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VAE_AMD_LIB') or os.path.join(_HERE, 'libvae_amd.so')  # env override: tuning builds only
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 VAE_OK, VAE_ERR_ARG, VAE_ERR_LAUNCH = 0, 1, 2
 VAE_F32, VAE_BF16 = 0, 1
@@ -70,6 +70,8 @@ SIGNATURES = {
     'vae_bnflow_stats_floats': [_i64],
     'vae_bnflow_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f, _i, _i, _i, _p],
     'vae_bnflow_bwd': [_p, _p, _p, _p, _p, _i64, _i64, _i, _i, _i, _p],
+    'vae_bnflow_bwd_sums': [_p, _p, _p, _p, _i64, _i64, _i, _i, _p],
+    'vae_bnflow_bwd_apply': [_p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _p],
 }
 
 _lib = None

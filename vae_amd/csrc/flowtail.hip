@@ -414,6 +414,19 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_kernel(
   if (mode == 1 && blockIdx.x == 0 && threadIdx.x == 0) o_gsum[0] = (float)gsum;
 }
 
+// Backward constants from column sums that the caller has reduced over every rank's rows (stats[6F, 8F]):
+// k1 = scale*S1/N, K = rstd*(scale*S2/N + GLD*rstd/N) with N the number of rows the statistics were taken over.
+__global__ __launch_bounds__(kBlock) void bn_bwd_consts_kernel(float* __restrict__ stats, int F, int64_t count) {
+  const int col = blockIdx.x * kBlock + threadIdx.x;
+  if (col >= F) return;
+  const double inv_n = 1.0 / (double)count;
+  const double sc = (double)stats[3 * (size_t)F + col], r = (double)stats[2 * (size_t)F + col];
+  const double s1 = (double)stats[6 * (size_t)F + col], s2 = (double)stats[7 * (size_t)F + col];
+  const double gsum = (double)stats[8 * (size_t)F];
+  stats[8 * (size_t)F + 4 + col] = (float)(sc * s1 * inv_n);
+  stats[9 * (size_t)F + 4 + col] = (float)(r * (sc * s2 * inv_n + gsum * inv_n * r));
+}
+
 // eval mode / explicit statistics: the per-column constants from given mean / var vectors
 __global__ __launch_bounds__(kBlock) void bn_prepare_kernel(const float* __restrict__ mean, const float* __restrict__ var,
                                                            const float* __restrict__ lg, const float* __restrict__ beta,
@@ -659,7 +672,7 @@ static int bn_fwd_dispatch(const void* x, const float* lg, const float* beta, co
                            float* stats, void* y, const void* ld_in, void* ld_out, int64_t B, int64_t F, float eps,
                            int training, int rev, hipStream_t st) {
   constexpr int VN = VecOf<T>::n;
-  const bool vec = (F % VN == 0) && aligned16(x) && aligned16(y) && aligned16(stats);
+  const bool vec = (F % VN == 0) && aligned16(x) && (!y || aligned16(y)) && aligned16(stats);
   float *mean = stats, *scale = stats + 3 * F, *shift = stats + 4 * F, *ldc = stats + 5 * F,
         *part = stats + 10 * F + 4;
   if (training) {
@@ -674,6 +687,7 @@ static int bn_fwd_dispatch(const void* x, const float* lg, const float* beta, co
                                tiles);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((F + kFinCols - 1) / kFinCols)), dim3(kBlock), 0, st, part,
                        grid, x, (int)(sizeof(T) == 2), lg, beta, stats, B, (int)F, eps, 0, 1);
+    if (!y) return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;  // statistics only
   } else {
     hipLaunchKernelGGL(bn_prepare_kernel, dim3((unsigned)((F + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, mean_in,
                        var_in, lg, beta, stats, (int)F);
@@ -695,23 +709,29 @@ static int bn_fwd_dispatch(const void* x, const float* lg, const float* beta, co
 
 template <typename T>
 static int bn_bwd_dispatch(const void* x, const void* gy, const void* gld, float* stats, void* gx, int64_t B, int64_t F,
-                           int training, int rev, hipStream_t st) {
+                           int training, int rev, int phase, int64_t count, hipStream_t st) {
   constexpr int VN = VecOf<T>::n;
-  const bool vec = (F % VN == 0) && aligned16(x) && aligned16(gy) && aligned16(gx) && aligned16(stats);
+  const bool vec = (F % VN == 0) && aligned16(x) && aligned16(gy) && (!gx || aligned16(gx)) && aligned16(stats);
   float *mean = stats, *rstd = stats + 2 * F, *scale = stats + 3 * F, *k1 = stats + 8 * F + 4, *kk = stats + 9 * F + 4,
         *part = stats + 10 * F + 4;
-  int G, NJ, grid;
-  int64_t tiles;
-  if (!bn_geom(B, vec ? F / VN : F, &G, &NJ, &tiles, &grid)) return VAE_ERR_ARG;
-  if (vec)
-    bn_colstats_launch<T, VN>(NJ, grid, st, (const T*)x, (const T*)gy, (const T*)gld, mean, rstd, part, B, (int)F, 1,
-                              rev, G, tiles);
-  else
-    bn_colstats_launch<T, 1>(NJ, grid, st, (const T*)x, (const T*)gy, (const T*)gld, mean, rstd, part, B, (int)F, 1, rev,
-                             G, tiles);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((F + kFinCols - 1) / kFinCols)), dim3(kBlock), 0, st, part, grid,
-                     (const void*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, stats, B, (int)F, 0.f, 1,
-                     training);
+  if (phase != 2) {
+    int G, NJ, grid;
+    int64_t tiles;
+    if (!bn_geom(B, vec ? F / VN : F, &G, &NJ, &tiles, &grid)) return VAE_ERR_ARG;
+    if (vec)
+      bn_colstats_launch<T, VN>(NJ, grid, st, (const T*)x, (const T*)gy, (const T*)gld, mean, rstd, part, B, (int)F, 1,
+                                rev, G, tiles);
+    else
+      bn_colstats_launch<T, 1>(NJ, grid, st, (const T*)x, (const T*)gy, (const T*)gld, mean, rstd, part, B, (int)F, 1,
+                               rev, G, tiles);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((F + kFinCols - 1) / kFinCols)), dim3(kBlock), 0, st, part,
+                       grid, (const void*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, stats, B, (int)F, 0.f,
+                       1, training);
+    if (phase == 1) return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;  // the three sums only
+  } else {
+    hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((unsigned)((F + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, stats,
+                       (int)F, count);
+  }
   const RowGeom g = row_geom(B, vec ? F / VN : F, kBnApplyGrid);
   const bool hoist = (vec ? F / VN : F) <= (int64_t)g.G * g.U;
 #define VAE_BN_BWD(VV, HH)                                                                                            \
@@ -791,7 +811,8 @@ int vae_bnflow_fwd(const void* x, const float* log_gamma, const float* beta, con
                    int training, int reverse, int dtype, vae_stream_t stream) {
   if (B < 0 || F <= 0 || F > VAE_MAX_BN_ROW) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
-  if (!x || !log_gamma || !beta || !stats || !y || !logdet_out) return VAE_ERR_ARG;
+  if (!x || !log_gamma || !beta || !stats) return VAE_ERR_ARG;
+  if ((!y || !logdet_out) && !(training && !y)) return VAE_ERR_ARG;  // y == NULL: training statistics only
   if (!training && (!mean_in || !var_in)) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32)
@@ -809,8 +830,30 @@ int vae_bnflow_bwd(const void* x, const void* gy, const void* glogdet, float* st
   if (B == 0) return VAE_OK;
   if (!x || !gy || !stats || !gx) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == VAE_F32) return bn_bwd_dispatch<float>(x, gy, glogdet, stats, gx, B, F, training, reverse, st);
-  if (dtype == VAE_BF16) return bn_bwd_dispatch<bf16_t>(x, gy, glogdet, stats, gx, B, F, training, reverse, st);
+  if (dtype == VAE_F32) return bn_bwd_dispatch<float>(x, gy, glogdet, stats, gx, B, F, training, reverse, 0, B, st);
+  if (dtype == VAE_BF16) return bn_bwd_dispatch<bf16_t>(x, gy, glogdet, stats, gx, B, F, training, reverse, 0, B, st);
+  return VAE_ERR_ARG;
+}
+
+int vae_bnflow_bwd_sums(const void* x, const void* gy, const void* glogdet, float* stats, int64_t B, int64_t F,
+                        int reverse, int dtype, vae_stream_t stream) {
+  if (B < 0 || F <= 0 || F > VAE_MAX_BN_ROW) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  if (!x || !gy || !stats) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VAE_F32) return bn_bwd_dispatch<float>(x, gy, glogdet, stats, nullptr, B, F, 1, reverse, 1, B, st);
+  if (dtype == VAE_BF16) return bn_bwd_dispatch<bf16_t>(x, gy, glogdet, stats, nullptr, B, F, 1, reverse, 1, B, st);
+  return VAE_ERR_ARG;
+}
+
+int vae_bnflow_bwd_apply(const void* x, const void* gy, float* stats, void* gx, int64_t B, int64_t F, int64_t count,
+                         int reverse, int dtype, vae_stream_t stream) {
+  if (B < 0 || F <= 0 || F > VAE_MAX_BN_ROW || count < B || count <= 0) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  if (!x || !gy || !stats || !gx) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VAE_F32) return bn_bwd_dispatch<float>(x, gy, nullptr, stats, gx, B, F, 1, reverse, 2, count, st);
+  if (dtype == VAE_BF16) return bn_bwd_dispatch<bf16_t>(x, gy, nullptr, stats, gx, B, F, 1, reverse, 2, count, st);
   return VAE_ERR_ARG;
 }
 

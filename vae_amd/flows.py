@@ -136,8 +136,10 @@ class MADESplit(_FlowLayer):
 
 
 class BatchNormFlow(_FlowLayer):
-    """flows/__init__.py:216-271.  The batch statistics are those of the rows this process holds (the reference
-    has no distributed form; SURVEY 8e leaves them local)."""
+    """flows/__init__.py:216-271.  On one device the batch statistics are those of the call's rows, as in the
+    reference.  When the batch is sharded, `vae_amd.dist.configure` sets `reduce_fn` and `inv_count` (= 1 / rows over
+    all ranks) and the statistics -- forward moments and the backward's column sums -- are those of the whole batch, so
+    an N-rank run equals the single-device run; leave them None for per-rank statistics."""
 
     def __init__(self, num_inputs, momentum=0.0, eps=1e-5):
         super(BatchNormFlow, self).__init__()
@@ -147,10 +149,15 @@ class BatchNormFlow(_FlowLayer):
         self.eps = eps
         self.register_buffer('running_mean', torch.zeros(num_inputs))
         self.register_buffer('running_var', torch.ones(num_inputs))
+        self.reduce_fn = None      # set by vae_amd.dist.configure: in-place sum of a small tensor over ranks
+        self.inv_count = None      # 1 / (rows over all ranks)
 
     def _step(self, inputs, cond_inputs, logdet_acc, reverse=False):
+        sync = self.training and self.reduce_fn is not None and self.inv_count is not None
         y, ld, mean, var = F_.bnflow(inputs, self.log_gamma, self.beta, self.running_mean, self.running_var,
-                                     logdet_in=logdet_acc, eps=self.eps, training=self.training, reverse=reverse)
+                                     logdet_in=logdet_acc, eps=self.eps, training=self.training, reverse=reverse,
+                                     reduce_fn=self.reduce_fn if sync else None,
+                                     count=int(round(1.0 / self.inv_count)) if sync else None)
         if self.training:
             self.batch_mean, self.batch_var = mean, var
             with torch.no_grad():

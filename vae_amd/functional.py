@@ -1107,8 +1107,12 @@ def coupling_tail(x, s_raw, t_raw, mask, logdet_in=None):
 
 
 class _BNFlow(torch.autograd.Function):
+    """reduce_fn / count: statistics over the rows of several ranks (`reduce_fn(t)` sums a small tensor over ranks in
+    place, `count` = rows over all ranks): local moments -> one reduction of 2F+1 doubles -> the apply; the backward
+    likewise reduces its 2F+1 column sums between its two kernels."""
+
     @staticmethod
-    def forward(ctx, x, log_gamma, beta, mean_in, var_in, logdet_in, eps, training, reverse):
+    def forward(ctx, x, log_gamma, beta, mean_in, var_in, logdet_in, eps, training, reverse, reduce_fn, count):
         ctx.set_materialize_grads(False)
         dev = check_device(x, log_gamma, beta, mean_in, var_in, logdet_in)
         B, F = x.shape
@@ -1116,40 +1120,70 @@ class _BNFlow(torch.autograd.Function):
         ld = torch.empty((B,), dtype=x.dtype, device=dev)
         stats = torch.empty((_lib.load().vae_bnflow_stats_floats(F),), dtype=torch.float32, device=dev)
         lg32, b32 = log_gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        sync = bool(training) and reduce_fn is not None and count is not None
         with _Guard(dev):
+            if sync:
+                # this rank's moments (y == NULL: no apply), summed over ranks as n*mean, n*E[x^2], n in double
+                pack = torch.zeros((2 * F + 1,), dtype=torch.float64, device=dev)
+                if B > 0:
+                    call('vae_bnflow_fwd', ptr(x), ptr(lg32), ptr(b32), None, None, ptr(stats), None, None, None, B, F,
+                         eps, 1, int(reverse), dtype_code(x), stream_ptr(dev))
+                    m, v = stats[:F].double(), stats[F:2 * F].double() - eps
+                    pack[:F] = m * B
+                    pack[F:2 * F] = (v + m * m) * B
+                    pack[2 * F] = B
+                reduce_fn(pack)
+                gmean = pack[:F] / count
+                gvar = pack[F:2 * F] / count - gmean * gmean + eps
+                mean_in, var_in = gmean.float().contiguous(), gvar.float().contiguous()
             call('vae_bnflow_fwd', ptr(x), ptr(lg32), ptr(b32), ptr(mean_in), ptr(var_in), ptr(stats), ptr(y),
-                 ptr(logdet_in), ptr(ld), B, F, eps, int(training), int(reverse), dtype_code(x), stream_ptr(dev))
+                 ptr(logdet_in), ptr(ld), B, F, eps, int(training and not sync), int(reverse), dtype_code(x),
+                 stream_ptr(dev))
         ctx.save_for_backward(x, lg32, stats)
-        ctx.cfg = (training, reverse, logdet_in is not None, log_gamma.dtype)
+        ctx.cfg = (training, reverse, logdet_in is not None, log_gamma.dtype, reduce_fn if sync else None, count)
         ctx.mark_non_differentiable(stats)
         return y, ld, stats
 
     @staticmethod
     def backward(ctx, gy, gld, _gstats):
         x, lg32, stats = ctx.saved_tensors
-        training, reverse, has_ld, pdt = ctx.cfg
+        training, reverse, has_ld, pdt, reduce_fn, count = ctx.cfg
         dev = x.device
         B, F = x.shape
         gld = _dense(gld)
         gy = torch.zeros_like(x) if gy is None else gy.contiguous()
         gx = torch.empty_like(x)
         with _Guard(dev):
-            call('vae_bnflow_bwd', ptr(x), ptr(gy), ptr(gld), ptr(stats), ptr(gx), B, F, int(training), int(reverse),
-                 dtype_code(x), stream_ptr(dev))
-        g_beta = stats[6 * F:7 * F].to(pdt)
-        g_lg = (torch.exp(lg32) * stats[7 * F:8 * F] + stats[8 * F]).to(pdt)
-        return gx, g_lg, g_beta, None, None, (gld if has_ld else None), None, None, None
+            if reduce_fn is None:
+                call('vae_bnflow_bwd', ptr(x), ptr(gy), ptr(gld), ptr(stats), ptr(gx), B, F, int(training),
+                     int(reverse), dtype_code(x), stream_ptr(dev))
+                sums = stats[6 * F:8 * F + 1]
+            else:
+                if B > 0:
+                    call('vae_bnflow_bwd_sums', ptr(x), ptr(gy), ptr(gld), ptr(stats), B, F, int(reverse),
+                         dtype_code(x), stream_ptr(dev))
+                else:
+                    stats[6 * F:8 * F + 1].zero_()
+                sums = stats[6 * F:8 * F + 1].clone()      # this rank's rows: the parameter gradients (DDP sums them)
+                reduce_fn(stats[6 * F:8 * F + 1])
+                call('vae_bnflow_bwd_apply', ptr(x), ptr(gy), ptr(stats), ptr(gx), B, F, int(count), int(reverse),
+                     dtype_code(x), stream_ptr(dev))
+        g_beta = sums[:F].to(pdt)
+        g_lg = (torch.exp(lg32) * sums[F:2 * F] + sums[2 * F]).to(pdt)
+        return gx, g_lg, g_beta, None, None, (gld if has_ld else None), None, None, None, None, None
 
 
 def bnflow(x, log_gamma, beta, running_mean=None, running_var=None, logdet_in=None, eps=1e-5, training=True,
-           reverse=False):
+           reverse=False, reduce_fn=None, count=None):
     """BatchNormFlow 'direct' (flows/__init__.py:233-257), optionally with the Reverse that follows it in a
     MAF block folded into the store.  Returns (y [B, F], logdet_out [B], batch_mean [F], batch_var [F]) --
-    the last two are what the caller folds into its running statistics (:240-246)."""
+    the last two are what the caller folds into its running statistics (:240-246).  With `reduce_fn` and `count`
+    (rows over all ranks) the batch statistics are those of the whole sharded batch."""
     x = x.contiguous()
     ld = None if logdet_in is None else logdet_in.reshape(-1).contiguous()
     F = x.shape[1]
     mi = None if training else running_mean.float().contiguous()
     vi = None if training else running_var.float().contiguous()
-    y, ldo, stats = _BNFlow.apply(x, log_gamma, beta, mi, vi, ld, float(eps), bool(training), bool(reverse))
+    y, ldo, stats = _BNFlow.apply(x, log_gamma, beta, mi, vi, ld, float(eps), bool(training), bool(reverse),
+                                  reduce_fn, count)
     return y, ldo, stats[:F], stats[F:2 * F]
