@@ -12,7 +12,8 @@
  *   - all pointers are DEVICE pointers unless stated; no torch types;
  *   - nothing here allocates, frees or synchronises: the caller owns every
  *     buffer, calls are asynchronous on `stream` (a hipStream_t, 0 = default);
- *   - `dtype` selects the tensor element type (VAE_F32 / VAE_BF16); arithmetic and
+ *   - `dtype` selects the tensor element type (VAE_F32 / VAE_BF16 / VAE_F16, the last for the reference's
+ *     `half=True` configs); arithmetic and
  *     reductions are always fp32 inside the kernels;
  *   - rows are samples.  `row_stride` / `stride_*` / `*_stride` are in ELEMENTS; tensors
  *     without a stride argument are contiguous; an output / gradient stride of 0 means
@@ -38,7 +39,7 @@ extern "C" {
 typedef void* vae_stream_t; /* hipStream_t */
 
 enum { VAE_OK = 0, VAE_ERR_ARG = 1, VAE_ERR_LAUNCH = 2 };
-enum { VAE_F32 = 0, VAE_BF16 = 1 };
+enum { VAE_F32 = 0, VAE_BF16 = 1, VAE_F16 = 2 };
 enum { VAE_NLL_BERNOULLI = 0, VAE_NLL_GAUSSIAN = 1, VAE_NLL_DISC_LOGISTIC = 2 };
 
 #define VAE_MAX_ROW (1 << 24) /* longest supported row (elements) */

@@ -66,7 +66,7 @@ def test_concat_large_vs_oracle():
 
 @pytest.mark.parametrize('B,L,K,Kb', [(7, 3, 5, 2), (300, 64, 128, 32), (1025, 36, 10, 20), (64, 512, 1024, 8)])
 @pytest.mark.parametrize('train', [True, False])
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_concat_fused_matches_per_child_path(B, L, K, Kb, train, dtype, monkeypatch):
     """The one-node Concat (children write strided slices of shared buffers) against the per-child
     path (narrow views + torch.cat) on the same injected noise: values and d(logits) bit-equal, since

@@ -164,13 +164,19 @@ def test_mixin_K_samples():
     close(out['elbo_mean'], ref['elbo_mean'], rtol=1e-5, atol=1e-3)
 
 
-def test_bf16_nll():
+@pytest.mark.parametrize('half', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('nll_type', ['bernoulli', 'gaussian', 'disc_logistic'])
+def test_bf16_nll(half, nll_type):
     torch.manual_seed(5)
-    x, recon = images(32, 1, 28, 28, 'bernoulli')
+    x, recon = images(32, 1, 28, 28, nll_type)
     from vae_amd import elbo as E
-    n1 = E.nll(x.to(DEV).bfloat16(), recon.to(DEV).bfloat16(), 'bernoulli')
-    n0 = O.nll(x, recon.bfloat16().float(), 'bernoulli')
-    assert n1.dtype == torch.bfloat16
+    n1 = E.nll(x.to(DEV).to(half), recon.to(DEV).to(half), nll_type)
+    n0 = O.nll(x.to(half).float(), recon.to(half).float(), nll_type)
+    assert n1.dtype == half
+    if half == torch.float16:            # per-sample sums beyond fp16's range come out as inf
+        big = n0 > 6e4
+        assert bool(torch.isinf(n1.cpu()[big]).all())
+        n1, n0 = n1.cpu().float().masked_fill(big, 0), n0.masked_fill(big, 0)
     close(n1, n0, rtol=1e-2, atol=1.0)
 
 
@@ -243,14 +249,14 @@ def test_fused_backward_matches_two_pass_and_oracle(nll_type, shape, upstream):
 
 
 @pytest.mark.parametrize('B,D', [(1, 1), (7, 3), (300, 784), (4096, 100), (3, 4099)])
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('gm', [(1.0, 0, 0, 0, 0, 0), (0.5, 0.25, 0.25, 0, 0, 0), (2.0, 1.0, -0.5, 3.0, 0.7, -1.5)])
 def test_fused_backward_one_launch_equals_finish_plus_combine(B, D, dtype, gm):
     """vae_nll_fused_backward == vae_nll_fused_grad_finish + vae_elbo_combine_bwd (the rescaled gradient bit for
     bit; the per-row constants to an ulp: the two kernels contract beta * g + g' differently)."""
     from vae_amd import _lib
     from vae_amd._lib import call, ptr
-    code = 0 if dtype == torch.float32 else 1
+    code = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[dtype]
     st = _lib.stream_ptr(torch.device(DEV))
     torch.manual_seed(B + D)
     g = torch.randn(B, D).to(dtype).to(DEV)
@@ -274,19 +280,20 @@ def test_fused_backward_one_launch_equals_finish_plus_combine(B, D, dtype, gm):
     close(keep, outs_a[1], rtol=1e-6 if dtype == torch.float32 else 1e-2, atol=0)
 
 
-def test_fused_backward_bf16_and_no_grad():
+@pytest.mark.parametrize('half', [torch.bfloat16, torch.float16])
+def test_fused_backward_bf16_and_no_grad(half):
     from vae_amd import elbo as E
     torch.manual_seed(4)
     x, recon = images(64, 1, 28, 28, 'bernoulli')
-    rd = recon.to(DEV).bfloat16().requires_grad_(True)
-    r = E.loss_function(rd, x.to(DEV).bfloat16(), None, 'bernoulli')
+    rd = recon.to(DEV).to(half).requires_grad_(True)
+    r = E.loss_function(rd, x.to(DEV).to(half), None, 'bernoulli')
     (g,) = torch.autograd.grad(r['loss_mean'], rd)
-    rc = recon.bfloat16().float().requires_grad_(True)
+    rc = recon.to(half).float().requires_grad_(True)
     r0 = O.loss_function(O.nll(x, rc, 'bernoulli'), torch.zeros(64))
     (g0,) = torch.autograd.grad(r0['loss_mean'], rc)
     close(g, g0, rtol=1e-2, atol=1e-4)
     with torch.no_grad():    # no graph: the plain forward kernel, no gradient buffer
-        r = E.loss_function(rd, x.to(DEV).bfloat16(), None, 'bernoulli')
+        r = E.loss_function(rd, x.to(DEV).to(half), None, 'bernoulli')
     assert not r['loss_mean'].requires_grad
 
 

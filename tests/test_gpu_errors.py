@@ -17,7 +17,7 @@ def test_dtype_and_device_are_checked():
     with pytest.raises(TypeError):
         F_.gauss_reparam_kl(torch.randn(4, 8, device=DEV, dtype=torch.float64), None)
     with pytest.raises(TypeError):
-        F_.gumbel_softmax(torch.randn(4, 8, device=DEV, dtype=torch.float16))
+        F_.gumbel_softmax(torch.randn(4, 8, device=DEV, dtype=torch.float64))
     with pytest.raises(RuntimeError):
         F_.gauss_kl(torch.randn(4, 8, device=DEV), torch.randn(4, 8))          # mixed devices
 

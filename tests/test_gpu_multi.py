@@ -116,7 +116,7 @@ def test_likelihood_golden(golden, name):
 
 
 @pytest.mark.parametrize('B,L,S', [(1, 1, 1), (7, 3, 2), (64, 128, 4), (1000, 36, 3), (257, 512, 5)])
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_gauss_multi_matches_single_calls(B, L, S, dtype):
     """S draws in one launch == S single-draw launches on the same noise: z bit-equal, KL/means equal,
     d(logits) equal up to the summation order over draws."""
@@ -153,6 +153,10 @@ def test_gauss_multi_matches_single_calls(B, L, S, dtype):
         # the single-call path adds S bf16-rounded gradients in bf16; judge the one-launch gradient (fp32
         # accumulation, one rounding) against the same computation on the upcast inputs instead
         g32 = run(False, up=True)[4]
+        if dtype == torch.float16:       # d KL / d s = s - 1/s beyond fp16's range: inf, as torch's own cast gives
+            big = g32.abs() > 6e4
+            assert bool(torch.isinf(g1[big]).all())
+            g1, g32 = g1.float().masked_fill(big, 0), g32.masked_fill(big, 0)
         close(g1, g32, rtol=1e-2, atol=1e-2)
 
 

@@ -14,10 +14,10 @@ import torch  # noqa: F401  (must be imported before the CDLL below, see module 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VAE_AMD_LIB') or os.path.join(_HERE, 'libvae_amd.so')  # env override: tuning builds only
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 VAE_OK, VAE_ERR_ARG, VAE_ERR_LAUNCH = 0, 1, 2
-VAE_F32, VAE_BF16 = 0, 1
+VAE_F32, VAE_BF16, VAE_F16 = 0, 1, 2
 NLL_TYPES = {'bernoulli': 0, 'gaussian': 1, 'disc_logistic': 2, 'log_logistic_256': 2}
 
 _p, _i64, _u64, _f, _i = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, ctypes.c_int
@@ -104,7 +104,9 @@ def dtype_code(t):
         return VAE_F32
     if t.dtype == torch.bfloat16:
         return VAE_BF16
-    raise TypeError("vae_amd kernels take float32 or bfloat16 tensors, got %s" % t.dtype)
+    if t.dtype == torch.float16:
+        return VAE_F16
+    raise TypeError("vae_amd kernels take float32, bfloat16 or float16 tensors, got %s" % t.dtype)
 
 
 def check_device(*tensors):

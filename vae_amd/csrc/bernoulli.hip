@@ -24,6 +24,10 @@ template <>
 struct ClampEps<bf16_t> {
   static constexpr float v = 0.0078125f;  // torch.finfo(bfloat16).eps
 };
+template <>
+struct ClampEps<f16_t> {
+  static constexpr float v = 0.0009765625f;  // torch.finfo(float16).eps
+};
 constexpr float kBernKlEps = 1e-6f;
 
 __device__ __forceinline__ float sigmoid_div(float v) { return rcp_nr(1.0f + expf(-v)); }
@@ -254,6 +258,7 @@ int vae_bernoulli_fwd(const void* logits, int64_t row_stride, const void* unif, 
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32) return bern_fwd_dispatch<float>(logits, row_stride, unif, y, y_stride, z_hard, z_hard_stride, B, K, tau, seed, offset, row0, st);
   if (dtype == VAE_BF16) return bern_fwd_dispatch<bf16_t>(logits, row_stride, unif, y, y_stride, z_hard, z_hard_stride, B, K, tau, seed, offset, row0, st);
+  if (dtype == VAE_F16) return bern_fwd_dispatch<f16_t>(logits, row_stride, unif, y, y_stride, z_hard, z_hard_stride, B, K, tau, seed, offset, row0, st);
   return VAE_ERR_ARG;
 }
 
@@ -274,6 +279,8 @@ int vae_bernoulli_bwd(const void* logits, int64_t row_stride, const void* y, int
                                                          gz_hard_stride, glogits, glogits_stride, B, K, tau, st);
   if (dtype == VAE_BF16) return bern_bwd_dispatch<bf16_t>(logits, row_stride, y, y_stride, gy, gy_stride, gz_hard,
                                                            gz_hard_stride, glogits, glogits_stride, B, K, tau, st);
+  if (dtype == VAE_F16) return bern_bwd_dispatch<f16_t>(logits, row_stride, y, y_stride, gy, gy_stride, gz_hard,
+                                                           gz_hard_stride, glogits, glogits_stride, B, K, tau, st);
   return VAE_ERR_ARG;
 }
 
@@ -287,6 +294,8 @@ int vae_bernoulli_kl_fwd(const void* logits_q, int64_t stride_q, const void* log
     return bern_kl_dispatch<float, false>(logits_q, stride_q, logits_p, stride_p, nullptr, kl, nullptr, nullptr, B, K, st);
   if (dtype == VAE_BF16)
     return bern_kl_dispatch<bf16_t, false>(logits_q, stride_q, logits_p, stride_p, nullptr, kl, nullptr, nullptr, B, K, st);
+  if (dtype == VAE_F16)
+    return bern_kl_dispatch<f16_t, false>(logits_q, stride_q, logits_p, stride_p, nullptr, kl, nullptr, nullptr, B, K, st);
   return VAE_ERR_ARG;
 }
 
@@ -301,6 +310,8 @@ int vae_bernoulli_kl_bwd(const void* logits_q, int64_t stride_q, const void* log
     return bern_kl_dispatch<float, true>(logits_q, stride_q, logits_p, stride_p, gkl, nullptr, g_logits_q, g_logits_p, B, K, st);
   if (dtype == VAE_BF16)
     return bern_kl_dispatch<bf16_t, true>(logits_q, stride_q, logits_p, stride_p, gkl, nullptr, g_logits_q, g_logits_p, B, K, st);
+  if (dtype == VAE_F16)
+    return bern_kl_dispatch<f16_t, true>(logits_q, stride_q, logits_p, stride_p, gkl, nullptr, g_logits_q, g_logits_p, B, K, st);
   return VAE_ERR_ARG;
 }
 

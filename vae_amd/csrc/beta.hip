@@ -358,6 +358,8 @@ int vae_beta_split_kl_fwd(const void* logits, int64_t row_stride, void* conc1, v
     return beta_split_fwd_dispatch<float>(logits, row_stride, conc1, conc2, kl, means, workspace, B, L, mean_scale, st);
   if (dtype == VAE_BF16)
     return beta_split_fwd_dispatch<bf16_t>(logits, row_stride, conc1, conc2, kl, means, workspace, B, L, mean_scale, st);
+  if (dtype == VAE_F16)
+    return beta_split_fwd_dispatch<f16_t>(logits, row_stride, conc1, conc2, kl, means, workspace, B, L, mean_scale, st);
   return VAE_ERR_ARG;
 }
 
@@ -372,6 +374,8 @@ int vae_beta_split_kl_bwd(const void* logits, int64_t row_stride, const void* gc
     return beta_split_bwd_dispatch<float>(logits, row_stride, gconc1, gconc2, gkl, gmeans, glogits, B, L, mean_scale, st);
   if (dtype == VAE_BF16)
     return beta_split_bwd_dispatch<bf16_t>(logits, row_stride, gconc1, gconc2, gkl, gmeans, glogits, B, L, mean_scale, st);
+  if (dtype == VAE_F16)
+    return beta_split_bwd_dispatch<f16_t>(logits, row_stride, gconc1, gconc2, gkl, gmeans, glogits, B, L, mean_scale, st);
   return VAE_ERR_ARG;
 }
 
@@ -387,6 +391,9 @@ int vae_beta_kl_fwd(const void* a1, int64_t stride_a1, const void* a0, int64_t s
                                           nullptr, nullptr, nullptr, nullptr, B, L, st);
   if (dtype == VAE_BF16)
     return beta_kl_dispatch<bf16_t, false>(a1, stride_a1, a0, stride_a0, b1, stride_b1, b0, stride_b0, nullptr, kl,
+                                           nullptr, nullptr, nullptr, nullptr, B, L, st);
+  if (dtype == VAE_F16)
+    return beta_kl_dispatch<f16_t, false>(a1, stride_a1, a0, stride_a0, b1, stride_b1, b0, stride_b0, nullptr, kl,
                                            nullptr, nullptr, nullptr, nullptr, B, L, st);
   return VAE_ERR_ARG;
 }
@@ -405,6 +412,9 @@ int vae_beta_kl_bwd(const void* a1, int64_t stride_a1, const void* a0, int64_t s
                                          ga0, gb1, gb0, B, L, st);
   if (dtype == VAE_BF16)
     return beta_kl_dispatch<bf16_t, true>(a1, stride_a1, a0, stride_a0, b1, stride_b1, b0, stride_b0, gkl, nullptr,
+                                          ga1, ga0, gb1, gb0, B, L, st);
+  if (dtype == VAE_F16)
+    return beta_kl_dispatch<f16_t, true>(a1, stride_a1, a0, stride_a0, b1, stride_b1, b0, stride_b0, gkl, nullptr,
                                           ga1, ga0, gb1, gb0, B, L, st);
   return VAE_ERR_ARG;
 }

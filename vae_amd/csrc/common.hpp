@@ -21,9 +21,27 @@ constexpr int kMaxGrid = 2048;  // 256 CUs x 8 resident workgroups; rows beyond 
 struct bf16_t {
   uint16_t bits;
 };
+struct f16_t {  // IEEE binary16: what the reference's `half=True` configs run in (helpers.utils.same_type)
+  uint16_t bits;
+};
+template <typename T>
+struct DTypeCode;
+template <>
+struct DTypeCode<float> {
+  static constexpr int value = 0;
+};
+template <>
+struct DTypeCode<bf16_t> {
+  static constexpr int value = 1;
+};
+template <>
+struct DTypeCode<f16_t> {
+  static constexpr int value = 2;
+};
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v.bits) << 16); }
+__device__ __forceinline__ float to_f32(f16_t v) { return (float)__builtin_bit_cast(_Float16, v.bits); }
 
 template <typename T>
 __device__ __forceinline__ T from_f32(float v);
@@ -36,6 +54,13 @@ __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) {
   // plain cast: hipcc emits v_cvt_pk_bf16_f32 (round-nearest-even, NaN stays NaN)
   __bf16 h = static_cast<__bf16>(v);
   bf16_t r;
+  r.bits = __builtin_bit_cast(uint16_t, h);
+  return r;
+}
+template <>
+__device__ __forceinline__ f16_t from_f32<f16_t>(float v) {
+  _Float16 h = static_cast<_Float16>(v);  // v_cvt_f16_f32: round-nearest-even, overflow to inf
+  f16_t r;
   r.bits = __builtin_bit_cast(uint16_t, h);
   return r;
 }
@@ -76,6 +101,10 @@ template <>
 struct PackOf<bf16_t, 8> {
   typedef uint32_t type __attribute__((ext_vector_type(4)));
 };
+template <>
+struct PackOf<f16_t, 8> {
+  typedef uint32_t type __attribute__((ext_vector_type(4)));
+};
 
 template <typename T>
 struct VecOf {
@@ -104,6 +133,12 @@ __device__ __forceinline__ void load_vec(const T* __restrict__ p, float (&out)[V
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
       for (int i = 0; i < V; ++i) out[i] = raw[i];
+    } else if constexpr (DTypeCode<T>::value == 2) {
+#pragma unroll
+      for (int i = 0; i < V / 2; ++i) {
+        out[2 * i] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw[i] & 0xffffu));
+        out[2 * i + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(raw[i] >> 16));
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < V / 2; ++i) {

@@ -468,6 +468,9 @@ int vae_nll_elbo_fwd(const void* x, const void* recon, int nll_type, const void*
   if (dtype == VAE_BF16)
     return nll_fwd_type<bf16_t>(nll_type, x, recon, kld, add, mi, nll, loss, elbo, means, workspace, B, D, kl_beta,
                                 inv_count, st);
+  if (dtype == VAE_F16)
+    return nll_fwd_type<f16_t>(nll_type, x, recon, kld, add, mi, nll, loss, elbo, means, workspace, B, D, kl_beta,
+                                inv_count, st);
   return VAE_ERR_ARG;
 }
 
@@ -483,6 +486,9 @@ int vae_nll_elbo_bwd(const void* x, const void* recon, int nll_type, const void*
                                kl_beta, inv_count, st);
   if (dtype == VAE_BF16)
     return nll_bwd_type<bf16_t>(nll_type, x, recon, gnll, gloss, gelbo, gmeans, grecon, gkld, gadd, gmi, B, D,
+                                kl_beta, inv_count, st);
+  if (dtype == VAE_F16)
+    return nll_bwd_type<f16_t>(nll_type, x, recon, gnll, gloss, gelbo, gmeans, grecon, gkld, gadd, gmi, B, D,
                                 kl_beta, inv_count, st);
   return VAE_ERR_ARG;
 }
@@ -501,11 +507,14 @@ int vae_nll_elbo_fused(const void* x, const void* recon, int nll_type, const voi
   if (dtype == VAE_BF16)
     return nll_fused_type<bf16_t>(nll_type, x, recon, kld, add, mi, nll, loss, elbo, means, workspace, grecon, cscale,
                                   B, D, kl_beta, inv_count, st);
+  if (dtype == VAE_F16)
+    return nll_fused_type<f16_t>(nll_type, x, recon, kld, add, mi, nll, loss, elbo, means, workspace, grecon, cscale,
+                                  B, D, kl_beta, inv_count, st);
   return VAE_ERR_ARG;
 }
 
 int vae_nll_fused_grad_finish(void* grecon, const float* gmeans, int64_t n, int dtype, vae_stream_t stream) {
-  if (n < 0 || (dtype != VAE_F32 && dtype != VAE_BF16)) return VAE_ERR_ARG;
+  if (n < 0 || (dtype != VAE_F32 && dtype != VAE_BF16 && dtype != VAE_F16)) return VAE_ERR_ARG;
   if (n == 0) return VAE_OK;
   if (!grecon || !gmeans) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -517,16 +526,19 @@ int vae_nll_fused_grad_finish(void* grecon, const float* gmeans, int64_t n, int 
   if (dtype == VAE_F32) {
     if (vec) hipLaunchKernelGGL((scale_by_mean_grads_kernel<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)grecon, gmeans, items);
     else hipLaunchKernelGGL((scale_by_mean_grads_kernel<float, 1>), dim3(grid), dim3(kBlock), 0, st, (float*)grecon, gmeans, items);
-  } else {
+  } else if (dtype == VAE_BF16) {
     if (vec) hipLaunchKernelGGL((scale_by_mean_grads_kernel<bf16_t, 8>), dim3(grid), dim3(kBlock), 0, st, (bf16_t*)grecon, gmeans, items);
     else hipLaunchKernelGGL((scale_by_mean_grads_kernel<bf16_t, 1>), dim3(grid), dim3(kBlock), 0, st, (bf16_t*)grecon, gmeans, items);
+  } else {
+    if (vec) hipLaunchKernelGGL((scale_by_mean_grads_kernel<f16_t, 8>), dim3(grid), dim3(kBlock), 0, st, (f16_t*)grecon, gmeans, items);
+    else hipLaunchKernelGGL((scale_by_mean_grads_kernel<f16_t, 1>), dim3(grid), dim3(kBlock), 0, st, (f16_t*)grecon, gmeans, items);
   }
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 
 int vae_nll_fused_backward(void* grecon, int64_t n, const float* gmeans, float kl_beta, float inv_count, void* gkld,
                            void* gadd, void* gmi, int64_t B, int dtype, vae_stream_t stream) {
-  if (n < 0 || B < 0 || (dtype != VAE_F32 && dtype != VAE_BF16)) return VAE_ERR_ARG;
+  if (n < 0 || B < 0 || (dtype != VAE_F32 && dtype != VAE_BF16 && dtype != VAE_F16)) return VAE_ERR_ARG;
   if (n == 0 && B == 0) return VAE_OK;
   if (!gmeans || (n > 0 && !grecon)) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -540,9 +552,12 @@ int vae_nll_fused_backward(void* grecon, int64_t n, const float* gmeans, float k
   if (dtype == VAE_F32) {
     if (vec) hipLaunchKernelGGL((nll_fused_backward_kernel<float, 4>), dim3(grid), dim3(kBlock), 0, st, (float*)grecon, gmeans, items, (float*)gkld, (float*)gadd, (float*)gmi, B, kl_beta, inv_count);
     else hipLaunchKernelGGL((nll_fused_backward_kernel<float, 1>), dim3(grid), dim3(kBlock), 0, st, (float*)grecon, gmeans, items, (float*)gkld, (float*)gadd, (float*)gmi, B, kl_beta, inv_count);
-  } else {
+  } else if (dtype == VAE_BF16) {
     if (vec) hipLaunchKernelGGL((nll_fused_backward_kernel<bf16_t, 8>), dim3(grid), dim3(kBlock), 0, st, (bf16_t*)grecon, gmeans, items, (bf16_t*)gkld, (bf16_t*)gadd, (bf16_t*)gmi, B, kl_beta, inv_count);
     else hipLaunchKernelGGL((nll_fused_backward_kernel<bf16_t, 1>), dim3(grid), dim3(kBlock), 0, st, (bf16_t*)grecon, gmeans, items, (bf16_t*)gkld, (bf16_t*)gadd, (bf16_t*)gmi, B, kl_beta, inv_count);
+  } else {
+    if (vec) hipLaunchKernelGGL((nll_fused_backward_kernel<f16_t, 8>), dim3(grid), dim3(kBlock), 0, st, (f16_t*)grecon, gmeans, items, (f16_t*)gkld, (f16_t*)gadd, (f16_t*)gmi, B, kl_beta, inv_count);
+    else hipLaunchKernelGGL((nll_fused_backward_kernel<f16_t, 1>), dim3(grid), dim3(kBlock), 0, st, (f16_t*)grecon, gmeans, items, (f16_t*)gkld, (f16_t*)gadd, (f16_t*)gmi, B, kl_beta, inv_count);
   }
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
@@ -564,6 +579,10 @@ int vae_elbo_combine_fwd(const void* nll, const void* kld, const void* add, cons
     hipLaunchKernelGGL((elbo_combine_fwd_kernel<bf16_t>), dim3(grid), dim3(kBlock), 0, st, (const bf16_t*)nll,
                        (const bf16_t*)kld, (const bf16_t*)add, (const bf16_t*)mi, (bf16_t*)loss, (bf16_t*)elbo,
                        means ? workspace : nullptr, inv_count, means, B, kl_beta);
+  } else if (dtype == VAE_F16) {
+    hipLaunchKernelGGL((elbo_combine_fwd_kernel<f16_t>), dim3(grid), dim3(kBlock), 0, st, (const f16_t*)nll,
+                       (const f16_t*)kld, (const f16_t*)add, (const f16_t*)mi, (f16_t*)loss, (f16_t*)elbo,
+                       means ? workspace : nullptr, inv_count, means, B, kl_beta);
   } else {
     return VAE_ERR_ARG;
   }
@@ -584,6 +603,10 @@ int vae_elbo_combine_bwd(const void* gloss, const void* gelbo, const float* gmea
   } else if (dtype == VAE_BF16) {
     hipLaunchKernelGGL((elbo_combine_bwd_kernel<bf16_t>), dim3(grid), dim3(kBlock), 0, st, (const bf16_t*)gloss,
                        (const bf16_t*)gelbo, gmeans, (bf16_t*)gnll, (bf16_t*)gkld, (bf16_t*)gadd, (bf16_t*)gmi, B,
+                       kl_beta, inv_count);
+  } else if (dtype == VAE_F16) {
+    hipLaunchKernelGGL((elbo_combine_bwd_kernel<f16_t>), dim3(grid), dim3(kBlock), 0, st, (const f16_t*)gloss,
+                       (const f16_t*)gelbo, gmeans, (f16_t*)gnll, (f16_t*)gkld, (f16_t*)gadd, (f16_t*)gmi, B,
                        kl_beta, inv_count);
   } else {
     return VAE_ERR_ARG;

@@ -163,6 +163,8 @@ int vae_flow_kl_fwd(const void* u, const void* logdet, int64_t R, void* kl, floa
     return flow_fwd_dispatch<float>(u, logdet, R, kl, mean_io, workspace, B, F, inv_count, cross_batch, phase, st);
   if (dtype == VAE_BF16)
     return flow_fwd_dispatch<bf16_t>(u, logdet, R, kl, mean_io, workspace, B, F, inv_count, cross_batch, phase, st);
+  if (dtype == VAE_F16)
+    return flow_fwd_dispatch<f16_t>(u, logdet, R, kl, mean_io, workspace, B, F, inv_count, cross_batch, phase, st);
   return VAE_ERR_ARG;
 }
 
@@ -174,6 +176,7 @@ int vae_flow_kl_bwd(const void* u, const void* gkl, const float* gsum, void* gu,
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32) return flow_bwd_dispatch<float>(u, gkl, gsum, gu, B, row_len, scale, st);
   if (dtype == VAE_BF16) return flow_bwd_dispatch<bf16_t>(u, gkl, gsum, gu, B, row_len, scale, st);
+  if (dtype == VAE_F16) return flow_bwd_dispatch<f16_t>(u, gkl, gsum, gu, B, row_len, scale, st);
   return VAE_ERR_ARG;
 }
 

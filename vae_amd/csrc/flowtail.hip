@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kBlock) void bn_colstats_kernel(
 //           k1 = scale*S1/B, K = rstd*(scale*S2/B + GLD*rstd/B)   (training; eval: both 0)
 constexpr int kFinCols = 8, kFinGroups = kBlock / kFinCols;
 __global__ __launch_bounds__(kBlock) void bn_finalize_kernel(
-    const float* __restrict__ part, int nparts, const void* __restrict__ x0, int x_is_bf16, const float* __restrict__ lg,
+    const float* __restrict__ part, int nparts, const void* __restrict__ x0, int x_dtype, const float* __restrict__ lg,
     const float* __restrict__ beta, float* __restrict__ stats, int64_t B, int F, float eps, int mode, int training) {
   __shared__ double l1[kFinGroups][kFinCols], l2[kFinGroups][kFinCols];
   __shared__ double lex[kBlock / 64];
@@ -391,7 +391,8 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_kernel(
     s1 = 0.0; s2 = 0.0;
     for (int g = 0; g < kFinGroups; ++g) { s1 += l1[g][cl]; s2 += l2[g][cl]; }
     if (mode == 0) {
-      const float c = x_is_bf16 ? to_f32(((const bf16_t*)x0)[col]) : ((const float*)x0)[col];
+      const float c = x_dtype == 1 ? to_f32(((const bf16_t*)x0)[col])
+                                   : x_dtype == 2 ? to_f32(((const f16_t*)x0)[col]) : ((const float*)x0)[col];
       const double m1 = s1 / (double)B;
       const float mean = (float)((double)c + m1);
       const float var = (float)(s2 / (double)B - m1 * m1) + eps;
@@ -686,7 +687,7 @@ static int bn_fwd_dispatch(const void* x, const float* lg, const float* beta, co
       bn_colstats_launch<T, 1>(NJ, grid, st, (const T*)x, nullptr, nullptr, nullptr, nullptr, part, B, (int)F, 0, 0, G,
                                tiles);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((F + kFinCols - 1) / kFinCols)), dim3(kBlock), 0, st, part,
-                       grid, x, (int)(sizeof(T) == 2), lg, beta, stats, B, (int)F, eps, 0, 1);
+                       grid, x, DTypeCode<T>::value, lg, beta, stats, B, (int)F, eps, 0, 1);
     if (!y) return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;  // statistics only
   } else {
     hipLaunchKernelGGL(bn_prepare_kernel, dim3((unsigned)((F + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, mean_in,
@@ -764,6 +765,8 @@ int vae_made_tail_fwd(const void* x, int64_t stride_x, const void* m, int64_t st
     return made_fwd_dispatch<float>(x, stride_x, m, stride_m, a, stride_a, u, logdet_in, logdet_out, B, F, pre_exp_tanh, st);
   if (dtype == VAE_BF16)
     return made_fwd_dispatch<bf16_t>(x, stride_x, m, stride_m, a, stride_a, u, logdet_in, logdet_out, B, F, pre_exp_tanh, st);
+  if (dtype == VAE_F16)
+    return made_fwd_dispatch<f16_t>(x, stride_x, m, stride_m, a, stride_a, u, logdet_in, logdet_out, B, F, pre_exp_tanh, st);
   return VAE_ERR_ARG;
 }
 
@@ -778,6 +781,8 @@ int vae_made_tail_bwd(const void* u, const void* a, int64_t stride_a, const void
     return made_bwd_dispatch<float>(u, a, stride_a, gu, glogdet, gx, gm, stride_gm, ga, stride_ga, B, F, pre_exp_tanh, st);
   if (dtype == VAE_BF16)
     return made_bwd_dispatch<bf16_t>(u, a, stride_a, gu, glogdet, gx, gm, stride_gm, ga, stride_ga, B, F, pre_exp_tanh, st);
+  if (dtype == VAE_F16)
+    return made_bwd_dispatch<f16_t>(u, a, stride_a, gu, glogdet, gx, gm, stride_gm, ga, stride_ga, B, F, pre_exp_tanh, st);
   return VAE_ERR_ARG;
 }
 
@@ -790,6 +795,7 @@ int vae_coupling_tail_fwd(const void* x, const void* s_raw, const void* t_raw, c
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32) return coupling_fwd_dispatch<float>(x, s_raw, t_raw, mask, y, logdet_in, logdet_out, B, F, st);
   if (dtype == VAE_BF16) return coupling_fwd_dispatch<bf16_t>(x, s_raw, t_raw, mask, y, logdet_in, logdet_out, B, F, st);
+  if (dtype == VAE_F16) return coupling_fwd_dispatch<f16_t>(x, s_raw, t_raw, mask, y, logdet_in, logdet_out, B, F, st);
   return VAE_ERR_ARG;
 }
 
@@ -801,6 +807,7 @@ int vae_coupling_tail_bwd(const void* x, const void* s_raw, const float* mask, c
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32) return coupling_bwd_dispatch<float>(x, s_raw, mask, gy, glogdet, gx, gs_raw, gt_raw, B, F, st);
   if (dtype == VAE_BF16) return coupling_bwd_dispatch<bf16_t>(x, s_raw, mask, gy, glogdet, gx, gs_raw, gt_raw, B, F, st);
+  if (dtype == VAE_F16) return coupling_bwd_dispatch<f16_t>(x, s_raw, mask, gy, glogdet, gx, gs_raw, gt_raw, B, F, st);
   return VAE_ERR_ARG;
 }
 
@@ -821,6 +828,9 @@ int vae_bnflow_fwd(const void* x, const float* log_gamma, const float* beta, con
   if (dtype == VAE_BF16)
     return bn_fwd_dispatch<bf16_t>(x, log_gamma, beta, mean_in, var_in, stats, y, logdet_in, logdet_out, B, F, eps,
                                    training, reverse, st);
+  if (dtype == VAE_F16)
+    return bn_fwd_dispatch<f16_t>(x, log_gamma, beta, mean_in, var_in, stats, y, logdet_in, logdet_out, B, F, eps,
+                                   training, reverse, st);
   return VAE_ERR_ARG;
 }
 
@@ -832,6 +842,7 @@ int vae_bnflow_bwd(const void* x, const void* gy, const void* glogdet, float* st
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32) return bn_bwd_dispatch<float>(x, gy, glogdet, stats, gx, B, F, training, reverse, 0, B, st);
   if (dtype == VAE_BF16) return bn_bwd_dispatch<bf16_t>(x, gy, glogdet, stats, gx, B, F, training, reverse, 0, B, st);
+  if (dtype == VAE_F16) return bn_bwd_dispatch<f16_t>(x, gy, glogdet, stats, gx, B, F, training, reverse, 0, B, st);
   return VAE_ERR_ARG;
 }
 
@@ -843,6 +854,7 @@ int vae_bnflow_bwd_sums(const void* x, const void* gy, const void* glogdet, floa
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32) return bn_bwd_dispatch<float>(x, gy, glogdet, stats, nullptr, B, F, 1, reverse, 1, B, st);
   if (dtype == VAE_BF16) return bn_bwd_dispatch<bf16_t>(x, gy, glogdet, stats, nullptr, B, F, 1, reverse, 1, B, st);
+  if (dtype == VAE_F16) return bn_bwd_dispatch<f16_t>(x, gy, glogdet, stats, nullptr, B, F, 1, reverse, 1, B, st);
   return VAE_ERR_ARG;
 }
 
@@ -854,6 +866,7 @@ int vae_bnflow_bwd_apply(const void* x, const void* gy, float* stats, void* gx, 
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VAE_F32) return bn_bwd_dispatch<float>(x, gy, nullptr, stats, gx, B, F, 1, reverse, 2, count, st);
   if (dtype == VAE_BF16) return bn_bwd_dispatch<bf16_t>(x, gy, nullptr, stats, gx, B, F, 1, reverse, 2, count, st);
+  if (dtype == VAE_F16) return bn_bwd_dispatch<f16_t>(x, gy, nullptr, stats, gx, B, F, 1, reverse, 2, count, st);
   return VAE_ERR_ARG;
 }
 

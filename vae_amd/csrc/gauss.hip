@@ -349,6 +349,9 @@ int vae_gauss_reparam_kl_fwd(const void* logits, int64_t row_stride, const void*
   if (dtype == VAE_BF16)
     return gauss_fwd_dispatch<bf16_t>(logits, row_stride, noise, z, z_stride, s_out, kl, means, workspace, B, L, eps_tol,
                                       mean_scale, training, seed, offset, row0, st);
+  if (dtype == VAE_F16)
+    return gauss_fwd_dispatch<f16_t>(logits, row_stride, noise, z, z_stride, s_out, kl, means, workspace, B, L, eps_tol,
+                                      mean_scale, training, seed, offset, row0, st);
   return VAE_ERR_ARG;
 }
 
@@ -370,6 +373,10 @@ int vae_gauss_reparam_kl_bwd(const void* logits, int64_t row_stride, const void*
     return gauss_bwd_dispatch<bf16_t>(logits, row_stride, noise, gz, gz_stride, gs, gkl, gmeans, glogits, glogits_stride,
                                       B, L, eps_tol,
                                       mean_scale, training, seed, offset, row0, st);
+  if (dtype == VAE_F16)
+    return gauss_bwd_dispatch<f16_t>(logits, row_stride, noise, gz, gz_stride, gs, gkl, gmeans, glogits, glogits_stride,
+                                      B, L, eps_tol,
+                                      mean_scale, training, seed, offset, row0, st);
   return VAE_ERR_ARG;
 }
 
@@ -385,6 +392,9 @@ int vae_gauss_kl_fwd(const void* mu_q, int64_t stride_mu_q, const void* s_q, int
                                         B, L, st);
   if (dtype == VAE_BF16)
     return gauss_kl_fwd_dispatch<bf16_t>(mu_q, stride_mu_q, s_q, stride_s_q, mu_p, stride_mu_p, s_p, stride_s_p, kl,
+                                         B, L, st);
+  if (dtype == VAE_F16)
+    return gauss_kl_fwd_dispatch<f16_t>(mu_q, stride_mu_q, s_q, stride_s_q, mu_p, stride_mu_p, s_p, stride_s_p, kl,
                                          B, L, st);
   return VAE_ERR_ARG;
 }
@@ -403,6 +413,9 @@ int vae_gauss_kl_bwd(const void* mu_q, int64_t stride_mu_q, const void* s_q, int
                                         g_mu_q, g_s_q, g_mu_p, g_s_p, B, L, st);
   if (dtype == VAE_BF16)
     return gauss_kl_bwd_dispatch<bf16_t>(mu_q, stride_mu_q, s_q, stride_s_q, mu_p, stride_mu_p, s_p, stride_s_p,
+                                         gkl, g_mu_q, g_s_q, g_mu_p, g_s_p, B, L, st);
+  if (dtype == VAE_F16)
+    return gauss_kl_bwd_dispatch<f16_t>(mu_q, stride_mu_q, s_q, stride_s_q, mu_p, stride_mu_p, s_p, stride_s_p,
                                          gkl, g_mu_q, g_s_q, g_mu_p, g_s_p, B, L, st);
   return VAE_ERR_ARG;
 }

@@ -384,6 +384,9 @@ int vae_gumbel_fwd(const void* logits, int64_t row_stride, const void* unif, voi
   if (dtype == VAE_BF16)
     return gumbel_fwd_dispatch<bf16_t>(logits, row_stride, unif, y, y_stride, z_hard, z_hard_stride, log_q_z, B, K, tau, seed, offset, row0,
                                        st);
+  if (dtype == VAE_F16)
+    return gumbel_fwd_dispatch<f16_t>(logits, row_stride, unif, y, y_stride, z_hard, z_hard_stride, log_q_z, B, K, tau, seed, offset, row0,
+                                       st);
   return VAE_ERR_ARG;
 }
 
@@ -403,6 +406,8 @@ int vae_gumbel_bwd(const void* y, int64_t y_stride, const void* log_q_z, const v
                                       glogits_stride, B, K, tau, st);
   if (dtype == VAE_BF16) return gumbel_bwd_dispatch<bf16_t>(y, y_stride, log_q_z, gy, gy_stride, gz_hard, gz_hard_stride, glog_q_z, glogits,
                                        glogits_stride, B, K, tau, st);
+  if (dtype == VAE_F16) return gumbel_bwd_dispatch<f16_t>(y, y_stride, log_q_z, gy, gy_stride, gz_hard, gz_hard_stride, glog_q_z, glogits,
+                                       glogits_stride, B, K, tau, st);
   return VAE_ERR_ARG;
 }
 
@@ -416,6 +421,8 @@ int vae_categorical_kl_fwd(const void* log_q, int64_t stride_q, const void* log_
     return cat_kl_dispatch<float, false>(log_q, stride_q, log_p, stride_p, nullptr, kl, nullptr, nullptr, B, K, st);
   if (dtype == VAE_BF16)
     return cat_kl_dispatch<bf16_t, false>(log_q, stride_q, log_p, stride_p, nullptr, kl, nullptr, nullptr, B, K, st);
+  if (dtype == VAE_F16)
+    return cat_kl_dispatch<f16_t, false>(log_q, stride_q, log_p, stride_p, nullptr, kl, nullptr, nullptr, B, K, st);
   return VAE_ERR_ARG;
 }
 
@@ -429,6 +436,8 @@ int vae_categorical_kl_bwd(const void* log_q, int64_t stride_q, const void* log_
     return cat_kl_dispatch<float, true>(log_q, stride_q, log_p, stride_p, gkl, nullptr, g_log_q, g_log_p, B, K, st);
   if (dtype == VAE_BF16)
     return cat_kl_dispatch<bf16_t, true>(log_q, stride_q, log_p, stride_p, gkl, nullptr, g_log_q, g_log_p, B, K, st);
+  if (dtype == VAE_F16)
+    return cat_kl_dispatch<f16_t, true>(log_q, stride_q, log_p, stride_p, gkl, nullptr, g_log_q, g_log_p, B, K, st);
   return VAE_ERR_ARG;
 }
 

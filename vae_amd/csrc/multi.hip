@@ -428,6 +428,9 @@ int vae_gauss_reparam_multi_fwd(const void* logits, int64_t row_stride, const vo
   if (dtype == VAE_BF16)
     return gauss_multi_fwd_dispatch<bf16_t>(logits, row_stride, noise, z, s_out, kl, means, workspace, B, L, (int)S,
                                             eps_tol, mean_scale, seed, offset, row0, st);
+  if (dtype == VAE_F16)
+    return gauss_multi_fwd_dispatch<f16_t>(logits, row_stride, noise, z, s_out, kl, means, workspace, B, L, (int)S,
+                                            eps_tol, mean_scale, seed, offset, row0, st);
   return VAE_ERR_ARG;
 }
 
@@ -444,6 +447,9 @@ int vae_gauss_reparam_multi_bwd(const void* logits, int64_t row_stride, const vo
                                            eps_tol, mean_scale, seed, offset, row0, st);
   if (dtype == VAE_BF16)
     return gauss_multi_bwd_dispatch<bf16_t>(logits, row_stride, noise, gz, gs, gkl, gmeans, glogits, B, L, (int)S,
+                                            eps_tol, mean_scale, seed, offset, row0, st);
+  if (dtype == VAE_F16)
+    return gauss_multi_bwd_dispatch<f16_t>(logits, row_stride, noise, gz, gs, gkl, gmeans, glogits, B, L, (int)S,
                                             eps_tol, mean_scale, seed, offset, row0, st);
   return VAE_ERR_ARG;
 }
@@ -467,6 +473,9 @@ int vae_nll_multi_elbo_fwd(const void* x, const void* const* recons, int64_t S, 
   if (dtype == VAE_BF16)
     return nll_multi_fwd_type<bf16_t>(nll_type, x, rp, al, (int)S, kld, add, mi, nll, loss, elbo, means, workspace, B,
                                       D, kl_beta, inv_count, st);
+  if (dtype == VAE_F16)
+    return nll_multi_fwd_type<f16_t>(nll_type, x, rp, al, (int)S, kld, add, mi, nll, loss, elbo, means, workspace, B,
+                                      D, kl_beta, inv_count, st);
   return VAE_ERR_ARG;
 }
 
@@ -487,6 +496,9 @@ int vae_nll_multi_elbo_bwd(const void* x, const void* const* recons, void* const
                                      D, kl_beta, inv_count, st);
   if (dtype == VAE_BF16)
     return nll_multi_bwd_type<bf16_t>(nll_type, x, rp, gp, al, (int)S, gnll, gloss, gelbo, gmeans, gkld, gadd, gmi,
+                                      B, D, kl_beta, inv_count, st);
+  if (dtype == VAE_F16)
+    return nll_multi_bwd_type<f16_t>(nll_type, x, rp, gp, al, (int)S, gnll, gloss, gelbo, gmeans, gkld, gadd, gmi,
                                       B, D, kl_beta, inv_count, st);
   return VAE_ERR_ARG;
 }

@@ -262,6 +262,11 @@ int vae_gauss_pair_fwd(const void* enc_logits, int64_t stride_enc, const void* p
                                      z_post, z_prior, logvar_post, logvar_prior, clamped_prior_logits, kl_pair,
                                      kl_prior, means, workspace, B, L, eps_tol, mean_scale, training, seed, offset,
                                      row0, st);
+  if (dtype == VAE_F16)
+    return pair_fwd_dispatch<f16_t>(enc_logits, stride_enc, prior_logits, stride_prior, noise_post, noise_prior,
+                                     z_post, z_prior, logvar_post, logvar_prior, clamped_prior_logits, kl_pair,
+                                     kl_prior, means, workspace, B, L, eps_tol, mean_scale, training, seed, offset,
+                                     row0, st);
   return VAE_ERR_ARG;
 }
 
@@ -283,6 +288,11 @@ int vae_gauss_pair_bwd(const void* enc_logits, int64_t stride_enc, const void* p
                                     offset, row0, st);
   if (dtype == VAE_BF16)
     return pair_bwd_dispatch<bf16_t>(enc_logits, stride_enc, prior_logits, stride_prior, noise_post, noise_prior,
+                                     gz_post, gz_prior, glogvar_post, glogvar_prior, gclamped, gkl_pair, gkl_prior,
+                                     gmeans, g_enc_logits, g_prior_logits, B, L, eps_tol, mean_scale, training, seed,
+                                     offset, row0, st);
+  if (dtype == VAE_F16)
+    return pair_bwd_dispatch<f16_t>(enc_logits, stride_enc, prior_logits, stride_prior, noise_post, noise_prior,
                                      gz_post, gz_prior, glogvar_post, glogvar_prior, gclamped, gkl_pair, gkl_prior,
                                      gmeans, g_enc_logits, g_prior_logits, B, L, eps_tol, mean_scale, training, seed,
                                      offset, row0, st);
