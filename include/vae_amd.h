@@ -97,7 +97,8 @@ int vae_gauss_kl_bwd(const void* mu_q, int64_t stride_mu_q, const void* s_q, int
  *   enc_logits, prior_logits [B, 2L] (strided); noise_* [B, L] or NULL (Philox; the prior
  *   uses stream id offset ^ 2^63); z_* [B, L] (NULL allowed when !training);
  *   logvar_post = enc[:, L:] + eps; clamped_prior_logits [B, 2L] = [mu_p | sigmoid(raw)];
- *   logvar_prior = sigmoid(raw) + eps; kl_pair [B]; kl_prior [B] or NULL;
+ *   logvar_prior = sigmoid(raw) + eps (either logvar output may be NULL: not written); kl_pair [B];
+ *   kl_prior [B] or NULL;
  *   means: 4 floats (mu_q, logvar_q, mu_p, logvar_p sums * mean_scale) or NULL.        */
 int vae_gauss_pair_fwd(const void* enc_logits, int64_t stride_enc, const void* prior_logits, int64_t stride_prior,
                        const void* noise_post, const void* noise_prior, void* z_post, void* z_prior,

@@ -79,6 +79,8 @@ def pair_fused(B, L):
     cfg = 'B=%d L=%d f32 (one VRNN step, fused)' % (B, L)
     timeit('gauss_pair_fwd', cfg, lambda: call('vae_gauss_pair_fwd', ptr(enc), 2 * L, ptr(pri), 2 * L, ptr(n1), ptr(n2), ptr(zq), ptr(zp), ptr(lvq), ptr(lvp), ptr(cl), ptr(klp), ptr(kl0), ptr(means), ptr(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st),
            B * (40 * L + 4))   # SURVEY: 2 logits 16L + 2 noise 8L + 2 z 8L + clamped prior logits 8L + kl
+    timeit('gauss_pair_fwd (no logvars)', cfg, lambda: call('vae_gauss_pair_fwd', ptr(enc), 2 * L, ptr(pri), 2 * L, ptr(n1), ptr(n2), ptr(zq), ptr(zp), None, None, ptr(cl), ptr(klp), ptr(kl0), ptr(means), ptr(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st),
+           B * (40 * L + 4))
     timeit('gauss_pair_bwd', cfg, lambda: call('vae_gauss_pair_bwd', ptr(enc), 2 * L, ptr(pri), 2 * L, ptr(n1), ptr(n2), ptr(zq), ptr(zp), None, None, None, ptr(gk), ptr(gk), None, ptr(ge), ptr(gp), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st),
            B * (48 * L + 8))   # 2 logits 16L + 2 noise 8L + 2 gz 8L + 2 glogits 16L
 

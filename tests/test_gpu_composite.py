@@ -232,6 +232,38 @@ def test_vrnn_golden(golden):
             assert agg[k] == pytest.approx(v)
 
 
+def test_vrnn_step_logvars_are_produced_on_first_read():
+    """The fused VRNN step writes neither logvar tensor: kld() uses the launch's own KLs and leaves them pending;
+    reading them gives the reference's values and a gradient path into the logits."""
+    from vae_amd import vrnn as V
+    from vae_amd.lazy import LazyParams
+    from vae_amd.reparameterizers import IsotropicGaussian
+    torch.manual_seed(8)
+    B, L = 37, 12
+    c = cfg(continuous_size=2 * L)
+    rep = IsotropicGaussian(c).train()
+    enc, pri = torch.randn(B, 2 * L), torch.randn(B, 2 * L)
+    nq, npr = torch.randn(B, L), torch.randn(B, L)
+    ed, pd = enc.to(DEV).requires_grad_(True), pri.to(DEV).requires_grad_(True)
+    lm = {'encoder_logits': ed, 'prior_logits': pd, 'x_features': None}
+    z, params = V.reparameterize(rep, lm, c, noise=(nq.to(DEV), npr.to(DEV)))
+    gq, gp = params['posterior']['gaussian'], params['prior']['gaussian']
+    assert isinstance(gq, LazyParams) and gq.is_pending('logvar') and gp.is_pending('logvar')
+    kl = V.kld(rep, params, {'use_prior_kl': True})
+    assert gq.is_pending('logvar') and gp.is_pending('logvar')          # the KLs did not need them
+    z0, p0 = O.vrnn_reparameterize(enc, pri, nq, npr)
+    close(kl, O.vrnn_kld(p0, use_prior_kl=True), rtol=1e-5, atol=1e-4)
+    assert torch.equal(gq['logvar'].cpu(), p0['posterior']['gaussian']['logvar'])
+    close(gp['logvar'], p0['prior']['gaussian']['logvar'], rtol=1e-6, atol=1e-7)
+    assert not gq.is_pending('logvar')
+    (g,) = torch.autograd.grad(gq['logvar'].sum() + gp['logvar'].sum(), [ed], allow_unused=True)
+    assert torch.equal(g[:, L:], torch.ones(B, L, device=DEV)) and float(g[:, :L].abs().max()) == 0.0
+    # a KL against some other prior dict is recomputed, not taken from the cache
+    other = {'gaussian': {'mu': gp['mu'].detach() + 1.0, 'logvar': gp['logvar'].detach()}}
+    k2 = rep.kl(params['posterior'], other)
+    assert not torch.allclose(k2, rep.kl(params['posterior'], params['prior']))
+
+
 def test_vrnn_time_batched_loss_vs_per_step_oracle():
     """T steps scored in one launch over [T*B] rows == the reference's per-step loop + _mean_map."""
     from vae_amd import vrnn as V

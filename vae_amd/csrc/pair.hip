@@ -81,8 +81,8 @@ __global__ __launch_bounds__(kBlock) void gauss_pair_fwd_kernel(
               store_vec<T, V>(z_q + o, zq);
               store_vec<T, V>(z_p + o, zp);
             }
-            store_vec<T, V>(lv_q + o, sq[u]);
-            store_vec<T, V>(lv_p + o, eq[u]);
+            if (lv_q) store_vec<T, V>(lv_q + o, sq[u]);
+            if (lv_p) store_vec<T, V>(lv_p + o, eq[u]);
             store_vec<T, V>(clamped + row * 2 * (int64_t)L + (int64_t)j * V, mp[u]);
             store_vec<T, V>(clamped + row * 2 * (int64_t)L + L + (int64_t)j * V, sp[u]);
           }
@@ -185,7 +185,7 @@ static int pair_fwd_dispatch(const void* enc, int64_t se, const void* pri, int64
                              int training, uint64_t seed, uint64_t offset, int64_t row0, hipStream_t stream) {
   constexpr int VN = VecOf<T>::n;
   const bool vec = (L % VN == 0) && (se % VN == 0) && (sp % VN == 0) && aligned16(enc) && aligned16(pri) &&
-                   aligned16(lvq) && aligned16(lvp) && aligned16(clamped) && (!nq || aligned16(nq)) &&
+                   (!lvq || aligned16(lvq)) && (!lvp || aligned16(lvp)) && aligned16(clamped) && (!nq || aligned16(nq)) &&
                    (!np || aligned16(np)) && (!zq || aligned16(zq)) && (!zp || aligned16(zp));
   const RowGeom g = row_geom(B, vec ? L / VN : L, means ? kGridReduce : kGridStream);
   float* ws = means ? workspace : nullptr;
@@ -249,7 +249,7 @@ int vae_gauss_pair_fwd(const void* enc_logits, int64_t stride_enc, const void* p
                        vae_stream_t stream) {
   if (B < 0 || L <= 0 || L > VAE_MAX_ROW) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
-  if (!enc_logits || !prior_logits || !logvar_post || !logvar_prior || !clamped_prior_logits || !kl_pair ||
+  if (!enc_logits || !prior_logits || !clamped_prior_logits || !kl_pair ||
       (training && (!z_post || !z_prior)) || (means && !workspace) || stride_enc < 2 * L || stride_prior < 2 * L)
     return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;

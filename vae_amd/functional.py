@@ -676,14 +676,16 @@ def flow_kl(u, logdet, inv_count=None, reduce_fn=None):
 # --------------------------------------------------------------------------------------
 class _GaussPair(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, enc, pri, noise_q, noise_p, eps_tol, training, with_prior_kl, seed, offset, row0, mean_scale):
+    def forward(ctx, enc, pri, noise_q, noise_p, eps_tol, training, with_prior_kl, seed, offset, row0, mean_scale,
+                want_logvars=True):
         ctx.set_materialize_grads(False)
         dev = check_device(enc, pri, noise_q, noise_p)
         B, L = enc.shape[0], enc.shape[1] // 2
         new = lambda *s: torch.empty(s, dtype=enc.dtype, device=dev)
         z_q = new(B, L) if training else None
         z_p = new(B, L) if training else None
-        lv_q, lv_p, clamped, kl_pair = new(B, L), new(B, L), new(B, 2 * L), new(B)
+        lv_q, lv_p = (new(B, L), new(B, L)) if want_logvars else (None, None)
+        clamped, kl_pair = new(B, 2 * L), new(B)
         kl_prior = new(B) if with_prior_kl else None
         means = _scalars(4, dev, B)
         if mean_scale is None:
@@ -702,6 +704,9 @@ class _GaussPair(torch.autograd.Function):
         if kl_prior is None:
             kl_prior = enc.new_empty((0,))
             nd.append(kl_prior)
+        if not want_logvars:        # produced on first read by the caller (vae_amd.vrnn) instead
+            lv_q, lv_p = enc.new_empty((0,)), enc.new_empty((0,))
+            nd += [lv_q, lv_p]
         if nd:
             ctx.mark_non_differentiable(*nd)
         return z_q, z_p, lv_q, lv_p, clamped, kl_pair, kl_prior, means
@@ -722,21 +727,24 @@ class _GaussPair(torch.autograd.Function):
                  ptr(_dense(gz_q)), ptr(_dense(gz_p)), ptr(_dense(glv_q)), ptr(_dense(glv_p)), ptr(_dense(gcl)),
                  ptr(_dense(gkl_pair)), ptr(_dense(gkl_prior)), ptr(gmeans), ptr(g_enc), ptr(g_pri), B, L, eps_tol,
                  mean_scale, int(training), seed & _MASK64, offset & _MASK64, row0, dtype_code(enc), stream_ptr(dev))
-        return g_enc, g_pri, None, None, None, None, None, None, None, None, None
+        return g_enc, g_pri, None, None, None, None, None, None, None, None, None, None
 
 
 def gauss_pair(enc_logits, prior_logits, noise_post=None, noise_prior=None, eps_tol=1e-6, training=True,
-               with_prior_kl=True, seed=0, offset=0, row0=0, mean_scale=None):
+               with_prior_kl=True, seed=0, offset=0, row0=0, mean_scale=None, want_logvars=True):
     """One VRNN step (vrnn.py:419-447 + :723-733) in one launch.  Returns (z_post, z_prior, logvar_post,
     logvar_prior, clamped_prior_logits, kl_pair, kl_prior, means[4]); z_* are None in eval (the caller
-    uses the mu views), kl_prior is None unless `with_prior_kl`."""
+    uses the mu views), kl_prior is None unless `with_prior_kl`, the logvars are None (not written) unless
+    `want_logvars`."""
     enc, pri = _rows(enc_logits), _rows(prior_logits)
     B, L = enc.shape[0], enc.shape[1] // 2
     nq = None if noise_post is None else noise_post.reshape(B, L).contiguous()
     np_ = None if noise_prior is None else noise_prior.reshape(B, L).contiguous()
     out = _GaussPair.apply(enc, pri, nq, np_, float(eps_tol), bool(training), bool(with_prior_kl), int(seed),
-                           int(offset), int(row0), mean_scale)
+                           int(offset), int(row0), mean_scale, bool(want_logvars))
     z_q, z_p, lv_q, lv_p, clamped, kl_pair, kl_prior, means = out
+    if not want_logvars:
+        lv_q = lv_p = None
     return ((z_q if training else None), (z_p if training else None), lv_q, lv_p, clamped, kl_pair,
             (kl_prior if with_prior_kl else None), means)
 

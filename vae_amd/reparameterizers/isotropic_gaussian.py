@@ -143,8 +143,8 @@ class IsotropicGaussian(nn.Module):
             if fused is not None and fused[1] is g['mu']:
                 return fused[0]
             return F_.gauss_kl(g['mu'], g['logvar'])
-        pair = getattr(g['logvar'], '_vae_amd_kl_pair', None)   # set by the fused VRNN step (vae_amd.vrnn)
-        if pair is not None and pair[1] is prior['gaussian']['logvar']:
+        pair = getattr(g, '_vae_amd_kl_pair', None)             # set by the fused VRNN step (vae_amd.vrnn)
+        if pair is not None and pair[1] is prior['gaussian']:
             return pair[0]
         return F_.gauss_kl(g['mu'], g['logvar'], prior['gaussian']['mu'], prior['gaussian']['logvar'])
 

@@ -13,6 +13,7 @@ import torch
 from . import functional as F_
 from . import rng
 from .elbo import _pack
+from .lazy import LazyParams
 from .reparameterizers.isotropic_gaussian import EPS_TOL, IsotropicGaussian
 
 
@@ -34,7 +35,7 @@ def reparameterize(reparameterizer, logits_map, config, noise=None):
 
     With an IsotropicGaussian reparameterizer on 2-D logits the whole step -- both draws, the variance
     clamp and both KLs -- is ONE fused launch (`functional.gauss_pair`); the KLs ride on the returned
-    logvar tensors so that `kld()` below costs nothing.  Anything else takes the generic two-call path."""
+    parameter dicts so that `kld()` below costs nothing, and the two logvar tensors are produced on first read.  Anything else takes the generic two-call path."""
     noise = (None, None) if noise is None else noise
     enc, pri = logits_map['encoder_logits'], logits_map['prior_logits']
     if isinstance(reparameterizer, IsotropicGaussian) and config['reparam_type'] == 'isotropic_gaussian' \
@@ -60,21 +61,25 @@ def _reparameterize_fused(rep, logits_map, config, noise, force=False):
         noise = tuple(n if n is not None else rng.captured_noise('normal', (enc.shape[0], L), enc) for n in noise)
     if training and (noise[0] is None or noise[1] is None):
         seed, offset = rng.next_call()
-    z_q, z_p, lv_q, lv_p, clamped, kl_pair, kl_prior, means = F_.gauss_pair(
+    z_q, z_p, _, _, clamped, kl_pair, kl_prior, means = F_.gauss_pair(
         enc, pri, noise[0], noise[1], eps_tol=EPS_TOL, training=training, with_prior_kl=True, seed=seed,
-        offset=offset, row0=rep.row_offset, mean_scale=rep.mean_scale)
+        offset=offset, row0=rep.row_offset, mean_scale=rep.mean_scale, want_logvars=False)
     mu_q = torch.narrow(enc, -1, 0, L)
     mu_p = torch.narrow(clamped, -1, 0, L)
     if not training:
         z_q, z_p = mu_q, mu_p
     means = means.to(enc.dtype)
-    lv_q._vae_amd_kl_pair = (kl_pair, lv_p)      # KL(post || prior), valid against exactly this prior
-    lv_p._vae_amd_kl = (kl_prior, mu_p)          # KL(prior || N(0,1))
+    g_q = LazyParams({'z': z_q, 'mu': mu_q, 'mu_mean': means[0], 'logvar_mean': means[1]})
+    g_p = LazyParams({'z': z_p, 'mu': mu_p, 'mu_mean': means[2], 'logvar_mean': means[3]})
+    # the logvar entries are the reference's own ops (isotropic_gaussian.py:124-125 on the encoder logits and on the
+    # clamped prior logits), run only if somebody reads them: both KLs already came out of the launch
+    g_q.set_lazy('logvar', lambda: torch.narrow(enc, -1, L, L) + EPS_TOL)
+    g_p.set_lazy('logvar', lambda: torch.narrow(clamped, -1, L, L) + EPS_TOL)
+    g_q._vae_amd_kl_pair = (kl_pair, g_p)        # KL(post || prior), valid against exactly this prior
+    g_p._vae_amd_kl = (kl_prior, mu_p)           # KL(prior || N(0,1))
     logits_map['prior_logits'] = clamped
-    params_q = {'z': z_q, 'logits': enc,
-                'gaussian': {'z': z_q, 'mu': mu_q, 'logvar': lv_q, 'mu_mean': means[0], 'logvar_mean': means[1]}}
-    params_p = {'z': z_p, 'logits': clamped,
-                'gaussian': {'z': z_p, 'mu': mu_p, 'logvar': lv_p, 'mu_mean': means[2], 'logvar_mean': means[3]}}
+    params_q = {'z': z_q, 'logits': enc, 'gaussian': g_q}
+    params_p = {'z': z_p, 'logits': clamped, 'gaussian': g_p}
     z = {'prior': z_p, 'posterior': z_q, 'x_features': logits_map['x_features']}
     return z, {'prior': params_p, 'posterior': params_q}
 
