@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kBlock) void gumbel_fwd_kernel(
       for (int k = 0; k < U; ++k)
         if (sub + k * G < nvec)
 #pragma unroll
-          for (int i = 0; i < V; ++i) s1 += expf(sub_rn(l[k][i], m1));
+          for (int i = 0; i < V; ++i) s1 += exp_acc(sub_rn(l[k][i], m1));
       s1 = row_sum(s1, G);
       lse = logf(s1);
     }
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void gumbel_bwd_kernel(
           for (int i = 0; i < V; ++i) {
             float v = 0.f;
             if (soft) v += itau * yv[k][i] * (gt[k][i] - dot);
-            if (glq) v += gq[k][i] - expf(q[k][i]) * sg;
+            if (glq) v += gq[k][i] - exp_acc(q[k][i]) * sg;
             o[i] = v;
           }
           store_vec<T, V>(glogits + row * gl_stride + (int64_t)j * V, o);
@@ -227,8 +227,10 @@ __global__ __launch_bounds__(kBlock) void gumbel_bwd_kernel(
 // OneHotCategorical(logits=.) normalises once more (logits - logsumexp): idempotent up to
 // rounding on an already normalised log_q_z, folded into the one log_softmax here.
 // ---------------------------------------------------------------------------
+// a -> log_softmax(a) in place; p receives softmax(a) from the SAME exponentials (exp(a - max) / sum: one exp per
+// element instead of a second exp(log_softmax)).
 template <typename T, int V, int U>
-__device__ __forceinline__ void row_log_softmax(float (&a)[U][V], int sub, int G, int nvec) {
+__device__ __forceinline__ void row_log_softmax(float (&a)[U][V], float (&p)[U][V], int sub, int G, int nvec) {
   float m = kNegInf;
 #pragma unroll
   for (int k = 0; k < U; ++k)
@@ -239,15 +241,21 @@ __device__ __forceinline__ void row_log_softmax(float (&a)[U][V], int sub, int G
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < U; ++k)
-    if (sub + k * G < nvec)
 #pragma unroll
-      for (int i = 0; i < V; ++i) s += expf(a[k][i] - m);
+    for (int i = 0; i < V; ++i) {
+      p[k][i] = exp_acc(a[k][i] - m);
+      if (sub + k * G < nvec) s += p[k][i];
+    }
   s = row_sum(s, G);
   const float lse = m + logf(s);
+  const float inv = rcp_nr(s);
 #pragma unroll
   for (int k = 0; k < U; ++k)
 #pragma unroll
-    for (int i = 0; i < V; ++i) a[k][i] -= lse;
+    for (int i = 0; i < V; ++i) {
+      a[k][i] -= lse;
+      p[k][i] *= inv;
+    }
 }
 
 template <typename T, int V, int U, bool BWD>
@@ -265,14 +273,15 @@ __global__ __launch_bounds__(kBlock) void categorical_kl_kernel(
     float la[U][V], lb[U][V];
     load_chunk<T, V, U>(a + r * stride_a, sub, G, nvec, la);
     load_chunk<T, V, U>(b + r * stride_b, sub, G, nvec, lb);
-    row_log_softmax<T, V, U>(la, sub, G, nvec);
-    row_log_softmax<T, V, U>(lb, sub, G, nvec);
+    float pa[U][V], pb[U][V];
+    row_log_softmax<T, V, U>(la, pa, sub, G, nvec);
+    row_log_softmax<T, V, U>(lb, pb, sub, G, nvec);
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < U; ++k)
       if (sub + k * G < nvec)
 #pragma unroll
-        for (int i = 0; i < V; ++i) s += expf(la[k][i]) * (la[k][i] - lb[k][i]);
+        for (int i = 0; i < V; ++i) s += pa[k][i] * (la[k][i] - lb[k][i]);
     s = row_sum(s, G);
     if (!live) continue;
     if constexpr (!BWD) {
@@ -286,9 +295,9 @@ __global__ __launch_bounds__(kBlock) void categorical_kl_kernel(
           float oa[V], ob[V];
 #pragma unroll
           for (int i = 0; i < V; ++i) {
-            const float p = expf(la[k][i]);
+            const float p = pa[k][i];
             oa[i] = gk * p * ((la[k][i] - lb[k][i]) - s);
-            ob[i] = gk * (expf(lb[k][i]) - p);
+            ob[i] = gk * (pb[k][i] - p);
           }
           store_vec<T, V>(ga + row * K + (int64_t)j * V, oa);
           if (gb) store_vec<T, V>(gb + row * K + (int64_t)j * V, ob);

@@ -12,17 +12,6 @@ constexpr float kBin = 1.0f / 256.0f;
 __device__ __forceinline__ float sigmoidf_(float v) { return fast_rcp(1.0f + __expf(-v)); }
 // sigmoid for the discretized logistic, whose two CDF values are subtracted from each other (an
 // ulp there is amplified by 1/P): accurate exp, near-correctly-rounded reciprocal.
-// e^x to ~1 ulp wherever 1 + e^x differs from 1 or from e^x: the product x*log2(e) is split into its rounded value
-// and the residual (fma) plus the low word of log2(e), v_exp_f32 takes the rounded part and the residual is applied
-// as a first-order correction -- 8 VALU ops against the 14 of ocml's expf (no ldexp / range selects: arguments
-// above 88 are clamped, results below the normal range flush, both invisible after the 1 + e).
-__device__ __forceinline__ float exp_acc(float x) {
-  x = fminf(x, 88.0f);
-  const float t = x * 1.44269502f;
-  const float r = __builtin_fmaf(x, 1.44269502f, -t) + x * 1.92596299e-8f;
-  const float e = __builtin_amdgcn_exp2f(t);
-  return __builtin_fmaf(e, r * kLn2, e);
-}
 __device__ __forceinline__ float sigmoid_acc(float v) { return rcp_nr(1.0f + exp_acc(-v)); }
 // softplus(v) = log(1 + e^v): linear above 20 (torch.nn.functional.softplus), series for tiny e^v
 __device__ __forceinline__ float softplusf_(float v) {
