@@ -30,7 +30,7 @@ struct ClampEps<f16_t> {
 };
 constexpr float kBernKlEps = 1e-6f;
 
-__device__ __forceinline__ float sigmoid_div(float v) { return rcp_nr(1.0f + expf(-v)); }
+__device__ __forceinline__ float sigmoid_div(float v) { return rcp_nr(1.0f + exp_acc(-v)); }
 
 template <typename T, int V, int U>
 __global__ __launch_bounds__(kBlock) void bernoulli_fwd_kernel(
@@ -60,7 +60,9 @@ __global__ __launch_bounds__(kBlock) void bernoulli_fwd_kernel(
           for (int i = 0; i < V; ++i) {
             const float p = fminf(fmaxf(to_f32(from_f32<T>(sigmoid_div(l[k][i]))), e), 1.0f - e);
             const float uu = fminf(fmaxf(u[k][i], e), 1.0f - e);
-            const float lg = (__logf(uu) - __logf(1.0f - uu) + __logf(p) - __logf(1.0f - p)) * itau;
+            // all four arguments lie in [eps, 1 - eps] (normal range): bare v_log_f32, and the two differences as
+            // differences of log2 so that one multiply by ln 2 / tau serves the whole logit
+            const float lg = ((log2_raw(uu) - log2_raw(1.0f - uu)) + (log2_raw(p) - log2_raw(1.0f - p))) * (kLn2 * itau);
             y[i] = to_f32(from_f32<T>(sigmoid_div(lg)));
             const float h = y[i] >= 0.5f ? 1.0f : 0.0f;
             zh[i] = add_rn(to_f32(from_f32<T>(sub_rn(h, y[i]))), y[i]);

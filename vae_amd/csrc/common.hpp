@@ -194,7 +194,7 @@ __device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcp
 // 1/d to ~0.5 ulp: v_rcp_f32 + one Newton step (3 instructions instead of the ~10 of an IEEE divide)
 __device__ __forceinline__ float rcp_nr(float d) {
   const float r = __builtin_amdgcn_rcpf(d);
-  return r * (2.0f - d * r);
+  return mul_rn(r, __builtin_fmaf(-d, r, 2.0f));   // spelled out: the same bits in every kernel that uses it
 }
 // ln(x) for x in the NORMAL float range: bare v_log_f32 (log2, 1 ulp) times ln 2.  hipcc's __logf wraps the
 // same instruction in denormal scaling and a compensated multiply (~12 VALU ops instead of 2), which made the
@@ -205,16 +205,17 @@ __device__ __forceinline__ float log2_raw(float x) { return __builtin_amdgcn_log
 __device__ __forceinline__ float fast_log(float x) { return kLn2 * __builtin_amdgcn_logf(x); }
 // e^x for x <= ~80 with a result in the normal range or flushing to 0 (bare v_exp_f32)
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
-// e^x to ~1 ulp wherever 1 + e^x differs from 1 or from e^x: the product x*log2(e) is split into its rounded value
-// and the residual (fma) plus the low word of log2(e), v_exp_f32 takes the rounded part and the residual is applied
-// as a first-order correction -- 8 VALU ops against the 14 of ocml's expf (no ldexp / range selects: arguments
-// above 88 are clamped, results below the normal range flush, both invisible after a 1 + e or in a softmax sum).
+// e^x to ~1 ulp: the product x*log2(e) is split into its rounded value and the residual (fma) plus the low word of
+// log2(e), v_exp_f32 takes the rounded part and the residual is applied as a first-order correction -- 8 VALU ops
+// against the 14 of ocml's expf (no ldexp / range selects).  Beyond |x| = 88 (and for +-inf, whose residual is NaN,
+// and NaN) the bare v_exp_f32 value is returned: inf / 0 / huge / NaN as they should be, where a last-ulp correction
+// means nothing.  Every product / fma is spelled out, so the bits are the same in every kernel that uses it.
 __device__ __forceinline__ float exp_acc(float x) {
-  x = fminf(x, 88.0f);
-  const float t = x * 1.44269502f;
-  const float r = __builtin_fmaf(x, 1.44269502f, -t) + x * 1.92596299e-8f;
+  const float t = mul_rn(x, 1.44269502f);
+  const float r = __builtin_fmaf(x, 1.92596299e-8f, __builtin_fmaf(x, 1.44269502f, -t));
   const float e = __builtin_amdgcn_exp2f(t);
-  return __builtin_fmaf(e, r * kLn2, e);
+  const float c = __builtin_fmaf(e, mul_rn(r, kLn2), e);
+  return fabsf(x) < 88.0f ? c : e;
 }
 // log(1 + e) for e in [0, 1]
 __device__ __forceinline__ float log1p_unit(float e) {

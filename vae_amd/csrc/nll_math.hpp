@@ -55,7 +55,7 @@ __device__ __forceinline__ float nll_dlog(float x, float a, float v) {
   const float m = sigmoidf_(a);
   const float isc = __expf(-fminf(fmaxf(v, -4.5f), 0.0f));
   const float t = (xq - m) * isc;
-  const float cp = sigmoid_acc(t + kBin * isc);
+  const float cp = sigmoid_acc(__builtin_fmaf(kBin, isc, t));
   const float cm = sigmoid_acc(t);
   return -fast_log(cp - cm + 1e-7f);
 }
@@ -64,7 +64,7 @@ __device__ __forceinline__ void nll_dlog_grad(float x, float a, float v, float& 
   const float m = sigmoidf_(a);
   const float isc = __expf(-fminf(fmaxf(v, -4.5f), 0.0f));
   const float t = (xq - m) * isc;
-  const float tp = t + kBin * isc;
+  const float tp = __builtin_fmaf(kBin, isc, t);
   const float cp = sigmoid_acc(tp);
   const float cm = sigmoid_acc(t);
   const float ip = rcp_nr(cp - cm + 1e-7f);
