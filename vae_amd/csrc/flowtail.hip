@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kBlock) void made_tail_fwd_kernel(
 #pragma unroll
             for (int i = 0; i < V; ++i) {
               const float ai = pre_tanh ? tanh_acc(av[k][i]) : av[k][i];
-              o[i] = (xv[k][i] - mv[k][i]) * expf(-ai);
+              o[i] = (xv[k][i] - mv[k][i]) * exp_acc(-ai);
               s -= ai;
             }
             store_vec<T, V>(u + row * F + (int64_t)j * V, o);
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void made_tail_bwd_kernel(
           for (int i = 0; i < V; ++i) {
             const float g = gu ? gv[k][i] : 0.f;
             const float ai = pre_tanh ? tanh_acc(av[k][i]) : av[k][i];
-            ox[i] = g * expf(-ai);
+            ox[i] = g * exp_acc(-ai);
             om[i] = -ox[i];
             float d = -uv[k][i] * g - gl;
             if (pre_tanh) d *= (1.0f - ai * ai);
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void coupling_tail_fwd_kernel(
               const float ls = s_raw ? mul_rn(sv[k][i], inv) : 0.f;
               // separate roundings, as the reference's x * exp(log_s) + t (flows/__init__.py:524-528): no FMA
               // contraction, so the vector and scalar instantiations agree bit for bit
-              o[i] = add_rn(s_raw ? mul_rn(xv[k][i], expf(ls)) : xv[k][i], mul_rn(tv[k][i], inv));
+              o[i] = add_rn(s_raw ? mul_rn(xv[k][i], exp_acc(ls)) : xv[k][i], mul_rn(tv[k][i], inv));
               s += ls;
             }
             store_vec<T, V>(y + row * F + (int64_t)j * V, o);
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kBlock) void coupling_tail_bwd_kernel(
           for (int i = 0; i < V; ++i) {
             const float g = gy ? gv[k][i] : 0.f;
             const float inv = 1.0f - mk[k][i];
-            const float e = s_raw ? expf(sv[k][i] * inv) : 1.0f;
+            const float e = s_raw ? exp_acc(sv[k][i] * inv) : 1.0f;
             ox[i] = g * e;
             os[i] = s_raw ? (g * xv[k][i] * e + gl) * inv : 0.f;
             ot[i] = g * inv;

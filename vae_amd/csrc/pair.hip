@@ -16,7 +16,7 @@ namespace vae {
 
 constexpr uint64_t kPriorStream = 0x8000000000000000ull;  // Philox stream id of the prior's draw
 
-__device__ __forceinline__ float sigmoid_p(float v) { return rcp_nr(1.0f + expf(-v)); }
+__device__ __forceinline__ float sigmoid_p(float v) { return rcp_nr(1.0f + exp_acc(-v)); }
 
 template <typename T, int V, int U>
 __global__ __launch_bounds__(kBlock) void gauss_pair_fwd_kernel(
