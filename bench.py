@@ -151,6 +151,7 @@ def main():
     glogits = torch.empty(B, 2 * L, **f32)
     ws = _lib.workspace(dev)
     st = _lib.stream_ptr(dev)
+    wsst = [ws, st]          # rebound to the capture stream's pair for the graph-replay variant
     inv_count = 1.0 / (B * world)
     mean_scale = 1.0 / (B * world * L)
     row0 = rank * B
@@ -171,6 +172,7 @@ def main():
         def mark(i):
             if ev is not None:
                 ev[i].record()
+        ws, st = wsst
         mark(0)
         call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, noise_arg[0], ptr(z), L, plogvar, ptr(kl), pmeans,
              ptr(ws), B, L, 1e-6, mean_scale, 1, 1234, step_no[0], row0, 0, st)
@@ -208,7 +210,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
+    # HIP events around every launch of every 5th timed step (BENCH_EVENT_EVERY=n: every n-th).  Each record is a
+    # barrier packet on the stream: bracketing all four launches of EVERY step costs 24 us per 380 us step (measured:
+    # 172.7 M samples/s against 184.0 M with one bracketed step per run), a fifth of the steps 0.4 %.
+    every = max(1, int(os.environ.get('BENCH_EVENT_EVERY', '5')))
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] if k % every == 0 else None
+              for k in range(args.steps)]
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -229,7 +236,8 @@ def main():
 
     # per-kernel average durations from the HIP events recorded on the launch stream during the timed steps
     seg = {'gauss_reparam_kl_fwd': (0, 1), names[1]: (1, 2), names[2]: (3, 4), 'gauss_reparam_kl_bwd': (4, 5)}
-    dur_ms = {n: sum(e[a].elapsed_time(e[b]) for e in events) / args.steps for n, (a, b) in seg.items()}
+    timed = [e for e in events if e is not None]
+    dur_ms = {n: sum(e[a].elapsed_time(e[b]) for e in timed) / len(timed) for n, (a, b) in seg.items()}
     sanity = float(scalars[0].item())
     if not (sanity == sanity):
         raise SystemExit('bench: loss_mean is NaN')
@@ -241,7 +249,8 @@ def main():
         noise_arg[0] = None
         for _ in range(args.warmup):
             step()
-        ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
+        ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] if k % every == 0 else None
+               for k in range(args.steps)]
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         for k in range(args.steps):
@@ -253,9 +262,34 @@ def main():
         philox_variant = {'value': B * args.steps / dt2, 'unit': 'samples/s', 'ms_per_step': dt2 / args.steps * 1e3,
                           'kernels': {}}
         for n, (a, b) in seg.items():
-            ms = sum(e[a].elapsed_time(e[b]) for e in ev2) / args.steps
+            t2e = [e for e in ev2 if e is not None]
+            ms = sum(e[a].elapsed_time(e[b]) for e in t2e) / len(t2e)
             philox_variant['kernels'][n] = {'avg_ms': round(ms, 5), 'algorithmic_bytes': ab2[n],
                                             'frac': round(ab2[n] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # the same launches recorded once into a HIP graph and replayed (injected noise only: a graph would freeze the
+    # Philox offset): what the launch gaps between the four kernels cost.  Reported beside the figure.
+    graph_replay = None
+    if world == 1 and not philox and not args.main_only:
+        side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side):
+            wsst[0], wsst[1] = _lib.workspace(dev), _lib.stream_ptr(dev)
+            step()                                   # warm the side stream's workspace outside the capture
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            wsst[1] = _lib.stream_ptr(dev)
+            step()
+        for _ in range(args.warmup):
+            graph.replay()
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            graph.replay()
+        torch.cuda.synchronize(dev)
+        dt3 = time.perf_counter() - t2
+        wsst[0], wsst[1] = ws, st
+        graph_replay = {'value': B * args.steps / dt3, 'unit': 'samples/s', 'ms_per_step': dt3 / args.steps * 1e3}
 
     # the same step through the drop-in classes (autograd Functions, torch allocator): not the timed region,
     # reported beside it so the cost of the Python boundary is visible
@@ -332,7 +366,8 @@ def main():
                                    % (B, 'NLL forward and gradient in one pass' if fused else 'two-pass NLL'),
                        'global_batch': B * world, 'latent': L, 'pixels': D, 'parallelism': 'dp%d' % world,
                        'noise': 'in-kernel Philox4x32-10' if philox else 'injected (resident in HBM)',
-                       'logvar_output': 'materialized' if args.materialize_logvar else 'on first read (not written)'},
+                       'logvar_output': 'materialized' if args.materialize_logvar else 'on first read (not written)',
+                       'kernel_timing': 'HIP events around each launch of %d of the %d timed steps' % (len(timed), args.steps)},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': kernels[dom]['achieved_GBs'],
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kernels[dom]['frac'], 'traffic': traffic},
             'kernels': kernels,
@@ -343,6 +378,7 @@ def main():
             'module_path': module_path,
             'philox_variant': philox_variant,
             'stock_torch_same_gpu': stock_torch,
+            'graph_replay': graph_replay,
         }
         if world == 1 and not args.no_cpu_baseline and not args.main_only:
             out['cpu_baseline'] = cpu_baseline()
