@@ -27,6 +27,7 @@ _pp = ctypes.POINTER(ctypes.c_void_p)   # host array of device pointers
 SIGNATURES = {
     'vae_abi_version': [],
     'vae_workspace_bytes': [],
+    'vae_tuning_set': [ctypes.c_char_p, _i64],
     'vae_gauss_reparam_kl_fwd': [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i64, _i64, _f, _f, _i, _u64, _u64, _i64, _i,
                                  _p],
     'vae_gauss_reparam_kl_bwd': [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _f, _f, _i, _u64, _u64, _i64,

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(kBlock) void bernoulli_fwd_kernel(
     int64_t y_stride, T* __restrict__ zh_out, int64_t zh_stride, int64_t B, int K, float tau, uint64_t seed, uint64_t offset, int64_t row0, int G,
     int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * K * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = K / V;
@@ -67,8 +68,8 @@ __global__ __launch_bounds__(kBlock) void bernoulli_fwd_kernel(
             const float h = y[i] >= 0.5f ? 1.0f : 0.0f;
             zh[i] = add_rn(to_f32(from_f32<T>(sub_rn(h, y[i]))), y[i]);
           }
-          store_vec<T, V>(y_out + row * y_stride + (int64_t)j * V, y);
-          if (zh_out) store_vec<T, V>(zh_out + row * zh_stride + (int64_t)j * V, zh);
+          store_vec<T, V>(nts, y_out + row * y_stride + (int64_t)j * V, y);
+          if (zh_out) store_vec<T, V>(nts, zh_out + row * zh_stride + (int64_t)j * V, zh);
         }
       }
     }
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(kBlock) void bernoulli_bwd_kernel(
     const T* __restrict__ gy, int64_t gy_stride, const T* __restrict__ gzh, int64_t gzh_stride,
     T* __restrict__ glogits, int64_t gl_stride, int64_t B, int K, float tau, int G, int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * K * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = K / V;
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void bernoulli_bwd_kernel(
             const float g = (gy ? g1[k][i] : 0.f) + (gzh ? g2[k][i] : 0.f);
             o[i] = pass * g * yv[k][i] * (1.0f - yv[k][i]) * itau;
           }
-          store_vec<T, V>(glogits + row * gl_stride + (int64_t)j * V, o);
+          store_vec<T, V>(nts, glogits + row * gl_stride + (int64_t)j * V, o);
         }
       }
     }
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(kBlock) void bernoulli_kl_kernel(
     const T* __restrict__ gkl, T* __restrict__ kl, T* __restrict__ gq, T* __restrict__ gp, int64_t B, int K, int G,
     int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * K * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = K / V;
@@ -173,9 +176,9 @@ __global__ __launch_bounds__(kBlock) void bernoulli_kl_kernel(
               }
             }
             if constexpr (BWD) {
-              store_vec<T, V>(gq + row * K + (int64_t)j * V, oq);
+              store_vec<T, V>(nts, gq + row * K + (int64_t)j * V, oq);
               if constexpr (HASP) {
-                if (gp) store_vec<T, V>(gp + row * K + (int64_t)j * V, op);
+                if (gp) store_vec<T, V>(nts, gp + row * K + (int64_t)j * V, op);
               }
             }
           }

@@ -137,6 +137,7 @@ __global__ __launch_bounds__(kBlock) void beta_split_fwd_kernel(
     const T* __restrict__ logits, int64_t row_stride, T* __restrict__ c1, T* __restrict__ c0, T* __restrict__ kl,
     float* __restrict__ ws, float mean_scale, float* __restrict__ means, int64_t B, int L, int G, int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * L * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = L / V;
@@ -162,8 +163,8 @@ __global__ __launch_bounds__(kBlock) void beta_split_fwd_kernel(
               acc[0] += a[k][i];
               acc[1] += b[k][i];
             }
-            store_vec<T, V>(c1 + row * L + (int64_t)j * V, a[k]);
-            store_vec<T, V>(c0 + row * L + (int64_t)j * V, b[k]);
+            store_vec<T, V>(nts, c1 + row * L + (int64_t)j * V, a[k]);
+            store_vec<T, V>(nts, c0 + row * L + (int64_t)j * V, b[k]);
           }
         }
       }
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(kBlock) void beta_split_bwd_kernel(
     const T* __restrict__ gkl, const float* __restrict__ gmeans, T* __restrict__ glogits, int64_t B, int L,
     float mean_scale, int G, int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * L * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = L / V;
@@ -212,8 +214,8 @@ __global__ __launch_bounds__(kBlock) void beta_split_bwd_kernel(
             o1[i] = s1 * (1.0f - s1) * ((gc1 ? g1[k][i] : 0.f) + gk * d1 + gm1);
             o0[i] = s0 * (1.0f - s0) * ((gc0 ? g0[k][i] : 0.f) + gk * d0 + gm0);
           }
-          store_vec<T, V>(grow + (int64_t)j * V, o1);
-          store_vec<T, V>(grow + L + (int64_t)j * V, o0);
+          store_vec<T, V>(nts, grow + (int64_t)j * V, o1);
+          store_vec<T, V>(nts, grow + L + (int64_t)j * V, o0);
         }
       }
     }
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(kBlock) void beta_kl_kernel(
     T* __restrict__ ga1, T* __restrict__ ga0, T* __restrict__ gb1, T* __restrict__ gb0, int64_t B, int L, int G,
     int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * L * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = L / V;
@@ -262,11 +265,11 @@ __global__ __launch_bounds__(kBlock) void beta_kl_kernel(
             }
             if constexpr (BWD) {
               const int64_t o = row * L + (int64_t)j * V;
-              store_vec<T, V>(ga1 + o, o1);
-              store_vec<T, V>(ga0 + o, o0);
+              store_vec<T, V>(nts, ga1 + o, o1);
+              store_vec<T, V>(nts, ga0 + o, o0);
               if (gb1) {
-                store_vec<T, V>(gb1 + o, p1);
-                store_vec<T, V>(gb0 + o, p0);
+                store_vec<T, V>(nts, gb1 + o, p1);
+                store_vec<T, V>(nts, gb0 + o, p0);
               }
             }
           }

@@ -6,8 +6,8 @@
 // the row length), each lane moves 16 bytes per access (4 x f32 or 8 x bf16) so
 // a wave issues 1 KiB coalesced requests, row reductions are wave64 shuffles
 // inside the group, and the few batch-level scalars (means) leave the kernel as
-// one partial per block that a one-block finalize kernel sums in a fixed order
-// (deterministic: no float atomics).
+// one partial per block, summed in a fixed order by the block that arrives last
+// (grid_reduce / grid_reduce_cluster below; deterministic: no float atomics).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,7 +16,6 @@
 namespace vae {
 
 constexpr int kBlock = 256;     // 4 waves per workgroup
-constexpr int kMaxGrid = 2048;  // 256 CUs x 8 resident workgroups; rows beyond are grid-strided
 
 struct bf16_t {
   uint16_t bits;
@@ -87,10 +86,15 @@ __device__ __forceinline__ float div_rn(float a, float b) {
 }
 
 // 16-byte packets: the widest per-lane access (global_load/store_dwordx4).  Every tensor on
-// this path is streamed exactly once per kernel, so loads and stores carry the non-temporal
-// hint (no reuse to keep in L2 / Infinity Cache).  Measured on MI355X (scripts/ab.py, interleaved
-// in one process, B=65536): nt loads +8..15 % on the gauss kernels, nt stores -5..-15 %, so
-// loads are non-temporal and stores are plain.
+// this path is streamed exactly once per kernel, so loads carry the non-temporal hint (no reuse
+// to keep in L2 / Infinity Cache): +8..15 % on the gauss kernels (r01, scripts/ab.py).  Stores are
+// non-temporal only when the launch is too large to be cache-resident (one [B, row] tensor of at
+// least kNtStoreMinBytes): measured r02 in the step sequence of bench.py, where every kernel
+// finds the caches cold, nt stores take 6 % off the whole step (gauss_bwd 135 -> 125 us, the
+// one-pass NLL 123 -> 114 us; scripts/membench.hip: 2R1W rows of 3136 B 112 -> 100 us), while on
+// small tensors that the next kernel reads back from L2 / Infinity Cache they cost up to 60 %
+// (gumbel K = 32).  Round 1 had measured nt stores as a loss because it looped each kernel alone
+// on a working set that the 256 MiB Infinity Cache partly held.
 template <typename T, int V>
 struct PackOf;
 template <>
@@ -114,9 +118,11 @@ struct VecOf {
 #ifndef VAE_NT_LOAD
 #define VAE_NT_LOAD 1
 #endif
-#ifndef VAE_NT_STORE
-#define VAE_NT_STORE 0
+#ifndef VAE_NT_STORE_MIN_BYTES
+#define VAE_NT_STORE_MIN_BYTES (32ll << 20)
 #endif
+constexpr long long kNtStoreMinBytes = VAE_NT_STORE_MIN_BYTES;
+__device__ __forceinline__ bool nt_stores(int64_t tensor_bytes) { return tensor_bytes >= kNtStoreMinBytes; }
 
 template <typename T, int V, bool NT = (VAE_NT_LOAD != 0)>
 __device__ __forceinline__ void load_vec(const T* __restrict__ p, float (&out)[V]) {
@@ -150,7 +156,7 @@ __device__ __forceinline__ void load_vec(const T* __restrict__ p, float (&out)[V
 }
 
 template <typename T, int V>
-__device__ __forceinline__ void store_vec(T* __restrict__ p, const float (&in)[V]) {
+__device__ __forceinline__ void store_vec(bool nts, T* __restrict__ p, const float (&in)[V]) {
   if constexpr (V == 1) {
     p[0] = from_f32<T>(in[0]);
   } else {
@@ -164,12 +170,24 @@ __device__ __forceinline__ void store_vec(T* __restrict__ p, const float (&in)[V
       for (int i = 0; i < V / 2; ++i)
         raw[i] = (uint32_t)from_f32<T>(in[2 * i]).bits | ((uint32_t)from_f32<T>(in[2 * i + 1]).bits << 16);
     }
-#if VAE_NT_STORE
-    __builtin_nontemporal_store(raw, reinterpret_cast<P*>(p));
-#else
-    *reinterpret_cast<P*>(p) = raw;
-#endif
+    if (nts) {   // uniform over the launch (a function of the kernel arguments): a scalar branch
+      // Spelled as the instruction: with __builtin_nontemporal_store here the two arms are merged into one plain
+      // store whatever is put between them (the hint is metadata, dropped when the stores are sunk into the join
+      // block).  The compiler does not count this store in its vmcnt bookkeeping, so a later counted wait may also
+      // wait for its acknowledgement; measured against a build with the builtin in every store (r02, step sequence):
+      // no difference, every load of a tile is issued before its first store.
+      // The s_nop is the wait state the hardware needs between a store of more than 64 bits and a VALU write of its
+      // data registers: the compiler pads its own stores, it cannot see this one (without it bernoulli_bwd stored
+      // values of the next chunk: tests/test_gpu_bigindex.py).
+      asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(reinterpret_cast<P*>(p)), "v"(raw) : "memory");
+    } else {
+      *reinterpret_cast<P*>(p) = raw;
+    }
   }
+}
+template <typename T, int V>
+__device__ __forceinline__ void store_vec(T* __restrict__ p, const float (&in)[V]) {
+  store_vec<T, V>(false, p, in);
 }
 
 // U row-chunks of one lane, all loads issued before any use: lane `sub` of a G-lane group owns
@@ -230,6 +248,15 @@ __device__ __forceinline__ float log1p_unit_any(float e) {
   return d == 0.0f ? e : fast_log(u) * (e * fast_rcp(d));
 }
 
+// Workgroup barrier for LDS traffic only.  __syncthreads() is a workgroup-scope fence as well: it puts
+// `s_waitcnt vmcnt(0)` in front of s_barrier, so every wave first waits until its global stores are acknowledged
+// -- 1.5-4 us for a wave that has just issued its row of output (r02: the block-level partial sums of the one-pass
+// NLL cost 4.7 us per launch with it, 1.1 us with nothing stored in front).  Nothing on this path hands global
+// memory from one wave of a block to another, so only the LDS writes have to be complete.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Sum / max over the G lanes that share a row (G power of two, <= 64).  After the
 // butterfly every lane of the group holds the result.
 __device__ __forceinline__ float group_sum(float v, int G) {
@@ -249,9 +276,9 @@ __device__ __forceinline__ float row_sum(float v, int G) {
   if (G <= 64) return group_sum(v, G);
   __shared__ float lds_s[kBlock / 64];
   v = group_sum(v, 64);
-  __syncthreads();  // the previous reduction's readers are done
+  lds_barrier();  // the previous reduction's readers are done
   if ((threadIdx.x & 63) == 0) lds_s[threadIdx.x >> 6] = v;
-  __syncthreads();
+  lds_barrier();
   float s = 0.f;
 #pragma unroll
   for (int w = 0; w < kBlock / 64; ++w) s += lds_s[w];
@@ -261,13 +288,50 @@ __device__ __forceinline__ float row_max(float v, int G) {
   if (G <= 64) return group_max(v, G);
   __shared__ float lds_m[kBlock / 64];
   v = group_max(v, 64);
-  __syncthreads();
+  lds_barrier();
   if ((threadIdx.x & 63) == 0) lds_m[threadIdx.x >> 6] = v;
-  __syncthreads();
+  lds_barrier();
   float s = lds_m[0];
 #pragma unroll
   for (int w = 1; w < kBlock / 64; ++w) s = fmaxf(s, lds_m[w]);
   return s;
+}
+
+// Wave totals by DPP (v_mov_b32_dpp: no LDS round trip, ~10 cycles a step where a ds_bpermute butterfly step costs
+// ~120): xor 1, xor 2 inside quads, half-mirror and mirror inside the 16-lane rows, then row_bcast15 / row_bcast31
+// carry the row totals up; lane 63 holds the sum of all 64 lanes in a fixed order and every lane gets it back through
+// a readlane.  All 64 lanes must be active.  Used where a latency chain ends in these sums (the closing blocks).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v) {
+  const uint64_t b = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROW_MASK, 0xf, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ float wave_total(float v) {
+  v += dpp_f<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f<0x141, 0xf>(v);   // row_half_mirror
+  v += dpp_f<0x140, 0xf>(v);   // row_mirror
+  v += dpp_f<0x142, 0xa>(v);   // row_bcast15 into rows 1 and 3
+  v += dpp_f<0x143, 0xc>(v);   // row_bcast31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+  v += dpp_d<0xB1, 0xf>(v);
+  v += dpp_d<0x4E, 0xf>(v);
+  v += dpp_d<0x141, 0xf>(v);
+  v += dpp_d<0x140, 0xf>(v);
+  v += dpp_d<0x142, 0xa>(v);
+  v += dpp_d<0x143, 0xc>(v);
+  const uint64_t b = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, 63);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 63);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -313,10 +377,10 @@ __device__ __forceinline__ void grid_reduce(float (&acc)[N], float* __restrict__
 
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    const float s = wave_sum(acc[k]);
+    const float s = wave_total(acc[k]);
     if (lane == 0) lds[wave][k] = s;
   }
-  __syncthreads();
+  lds_barrier();
   if (wave != 0) return;
   if (lane < N) {
     float s = 0.f;
@@ -373,11 +437,57 @@ __device__ __forceinline__ void grid_reduce(float (&acc)[N], float* __restrict__
   }
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    double x = v[k];
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    const double x = wave_sum_d(v[k]);
     if (lane == 0) out[k] = (float)(x * (double)scale);
   }
   if (lane == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+
+// Thread-level double sums -> out[k] = scale * total, for a closing launch of a few blocks (gridDim.x <= 64: one
+// counter): block sums through LDS, one 8-double partial per block in the workspace's partial area, added in block
+// order by the block that arrives last.  Same hand-off as grid_reduce.  Every thread of the block calls it.
+template <int N>
+__device__ __forceinline__ void close_block_sums_d(double (&v)[N], float* __restrict__ ws, float scale,
+                                                   float* __restrict__ out) {
+  __shared__ double ldsd[kBlock / 64][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double x = wave_sum_d(v[k]);
+    if (lane == 0) ldsd[wave][k] = x;
+  }
+  lds_barrier();
+  if (wave != 0) return;
+  double mine = 0.0;
+  if (lane < N) {
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) mine += ldsd[w][lane];
+  }
+  const int grid = gridDim.x;
+  if (grid == 1) {
+    if (lane < N) out[lane] = (float)(mine * (double)scale);
+    return;
+  }
+  unsigned int* master = reinterpret_cast<unsigned int*>(ws);
+  double* cpart = reinterpret_cast<double*>(ws + 1024);
+  if (lane < N) __hip_atomic_store(&cpart[(size_t)blockIdx.x * 8 + lane], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned int t = 0;
+  if (lane == 0)
+    t = __hip_atomic_fetch_add(master, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)(grid - 1);
+  t = __builtin_amdgcn_readfirstlane(t);
+  asm volatile("" ::: "memory");
+  if (!t) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double x = lane < grid ? cpart[(size_t)lane * 8 + k] : 0.0;
+    x = wave_sum_d(x);
+    if (lane == 0) out[k] = (float)(x * (double)scale);
+  }
+  if (lane == 0) __hip_atomic_store(master, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Philox4x32-10 counter RNG (Salmon et al. 2011), used when the caller passes no
@@ -461,12 +571,30 @@ __device__ __forceinline__ void philox_uniform(uint64_t seed, uint64_t stream, u
 }
 
 // ---- host-side launch geometry -------------------------------------------------
+// Tuning overrides, read from the environment ONCE (first launch) and settable in-process through
+// vae_tuning_set (scripts/ab.py); 0 = the built-in choice.
+struct Knobs {
+  int G = 0;            // VAE_AMD_G        lanes per row
+  int U = 0;            // VAE_AMD_U        row-chunks in flight per lane
+  int64_t maxgrid = 0;  // VAE_AMD_MAXGRID  grid cap
+};
+inline Knobs& knobs() {
+  static Knobs k = [] {
+    Knobs r;
+    if (const char* e = getenv("VAE_AMD_G")) r.G = atoi(e);
+    if (const char* e = getenv("VAE_AMD_U")) r.U = atoi(e);
+    if (const char* e = getenv("VAE_AMD_MAXGRID")) r.maxgrid = atoll(e);
+    return r;
+  }();
+  return k;
+}
+
 struct RowGeom {
   int G;               // lanes per row
   int U;               // row-chunks loaded up front per lane (1, 2 or 4)
   int rows_per_block;  // kBlock / G
   int64_t tiles;       // ceil(rows / rows_per_block)
-  int grid;            // min(tiles, kMaxGrid)
+  int grid;            // min(tiles, max_grid); tiles beyond are grid-strided
 };
 
 // Lanes per row: a whole wave (G = 64: 1 KiB contiguous per load/store instruction) once the
@@ -475,30 +603,22 @@ struct RowGeom {
 // (scripts/ab.py): for 784-pixel rows G = 64 beats G = 8/16 by 20-45 % on the store-heavy
 // backward although 23 % of the lane slots of the last pass idle.
 // Grid: one tile per block (measured: +8 % over a 2048-block grid-stride loop); kernels that
-// also reduce batch scalars are capped at kReduceGridMax blocks (the partials buffer).
-// VAE_AMD_G / VAE_AMD_U / VAE_AMD_MAXGRID override (tuning only).
+// reduce batch scalars with grid_reduce are capped at kGridReduce blocks.
 constexpr int kGridReduce = 1024;  // measured: the per-block ticket costs more than it saves beyond ~4 blocks/CU
 constexpr int64_t kGridStream = 1 << 20;
 
 inline RowGeom row_geom(int64_t rows, int64_t vecs_per_row, int64_t max_grid = kGridReduce) {
+  const Knobs& kn = knobs();
   RowGeom g;
   int G = 1;
   while (G < 64 && (int64_t)G * 2 < vecs_per_row) G <<= 1;  // >= 2 vectors per lane and tensor in flight
-  if (const char* e = getenv("VAE_AMD_G")) {
-    const int v = atoi(e);
-    if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) G = v;
-  }
+  if (kn.G >= 1 && kn.G <= 64 && (kn.G & (kn.G - 1)) == 0) G = kn.G;
   g.G = G;
   const int64_t iters = (vecs_per_row + G - 1) / G;
   g.U = iters >= 3 ? 4 : (iters == 2 ? 2 : 1);
-  if (const char* e = getenv("VAE_AMD_U")) {
-    const int v = atoi(e);
-    if (v == 1 || v == 2 || v == 4) g.U = v;
-  }
-  if (const char* e = getenv("VAE_AMD_MAXGRID")) {
-    const int64_t v = atoll(e);
-    if (v >= 1) max_grid = (max_grid <= kReduceGridMax && v > kReduceGridMax) ? kReduceGridMax : v;
-  }
+  if (kn.U == 1 || kn.U == 2 || kn.U == 4) g.U = kn.U;
+  if (kn.maxgrid >= 1)
+    max_grid = (max_grid <= kReduceGridMax && kn.maxgrid > kReduceGridMax) ? kReduceGridMax : kn.maxgrid;
   g.rows_per_block = kBlock / G;
   g.tiles = (rows + g.rows_per_block - 1) / g.rows_per_block;
   g.grid = (int)(g.tiles < max_grid ? g.tiles : max_grid);

@@ -38,20 +38,24 @@ constexpr bool kNtNllFwd = VAE_NT_NLL_FWD != 0, kNtNllBwd = VAE_NT_NLL_BWD != 0;
 template <typename T, int V, int NLL, int U>
 __global__ __launch_bounds__(kBlock) void nll_elbo_fwd_kernel(
     const T* __restrict__ x, const T* __restrict__ recon, const T* __restrict__ kld, const T* __restrict__ add,
-    const T* __restrict__ mi, T* __restrict__ nll_out, T* __restrict__ loss, T* __restrict__ elbo,
-    float* __restrict__ ws, float inv_count, float* __restrict__ means, int64_t B, int D, float kl_beta, int G,
-    int64_t tiles) {
+    const T* __restrict__ mi, T* __restrict__ nll_out, T* __restrict__ loss, T* __restrict__ elbo, int64_t B, int D,
+    float kl_beta, int G, int64_t tiles) {
   const int rpb = kBlock / G;
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = D / V;
   const int64_t rstride = (NLL == VAE_NLL_BERNOULLI) ? (int64_t)D : 2 * (int64_t)D;
-  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
     const int64_t row = t * rpb + rloc;
     float s = 0.f;
+    float k = 0.f, ad = 0.f, m = 0.f;   // requested with the row (see nll_elbo_fused_kernel)
     if (row < B) {
+      if (loss) {
+        if (kld) k = to_f32(kld[row]);
+        if (add) ad = to_f32(add[row]);
+        if (mi) m = to_f32(mi[row]);
+      }
       const T* xr = x + row * D;
       const T* rr = recon + row * rstride;
       for (int j0 = sub; j0 < nvec; j0 += G * U) {
@@ -78,18 +82,13 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_fwd_kernel(
       const float n = to_f32(from_f32<T>(s));
       nll_out[row] = from_f32<T>(n);
       if (loss) {
-        const float k = kld ? to_f32(kld[row]) : 0.f;
-        const float ad = add ? to_f32(add[row]) : 0.f;
-        const float m = mi ? to_f32(mi[row]) : 0.f;
         const float e = to_f32(from_f32<T>(n + k));
         const float l = to_f32(from_f32<T>((n + ad + kl_beta * k) - m));
         loss[row] = from_f32<T>(l);
         elbo[row] = from_f32<T>(e);
-        acc[0] += l; acc[1] += e; acc[2] += n; acc[3] += k; acc[4] += ad; acc[5] += m;
       }
     }
   }
-  if (ws) grid_reduce<6>(acc, ws, inv_count, means);
 }
 
 // ---------------------------------------------------------------------------
@@ -103,6 +102,7 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_bwd_kernel(
     T* __restrict__ gadd, T* __restrict__ gmi, int64_t B, int D, float kl_beta, float inv_count, int G,
     int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * D * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = D / V;
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_bwd_kernel(
               ga[i] *= c; gb[i] *= c;
             }
           }
-          store_vec<T, V>(gr + (int64_t)j * V, ga);
-          if constexpr (NLL != VAE_NLL_BERNOULLI) store_vec<T, V>(gr + D + (int64_t)j * V, gb);
+          store_vec<T, V>(nts, gr + (int64_t)j * V, ga);
+          if constexpr (NLL != VAE_NLL_BERNOULLI) store_vec<T, V>(nts, gr + D + (int64_t)j * V, gb);
         }
       }
     }
@@ -210,27 +210,36 @@ template <typename T, int V, int NLL, int U>
 __global__ __launch_bounds__(kBlock) void nll_elbo_fused_kernel(
     const T* __restrict__ x, const T* __restrict__ recon, const T* __restrict__ kld, const T* __restrict__ add,
     const T* __restrict__ mi, T* __restrict__ nll_out, T* __restrict__ loss, T* __restrict__ elbo,
-    float* __restrict__ ws, float inv_count, float* __restrict__ means, T* __restrict__ grecon, float cscale,
-    int64_t B, int D, float kl_beta, int G, int64_t tiles) {
+    T* __restrict__ grecon, float cscale, int64_t B, int D, float kl_beta, int G, int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * D * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = D / V;
   const int64_t rstride = (NLL == VAE_NLL_BERNOULLI) ? (int64_t)D : 2 * (int64_t)D;
-  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
     const int64_t row = t * rpb + rloc;
     float s = 0.f;
+    // the [B] inputs of the row epilogue, requested with the row itself (behind the row sum they were a dependent
+    // round trip with nothing else of the wave in flight)
+    float k = 0.f, ad = 0.f, m = 0.f;
     if (row < B) {
+      if (kld) k = to_f32(kld[row]);
+      if (add) ad = to_f32(add[row]);
+      if (mi) m = to_f32(mi[row]);
       const T* xr = x + row * D;
       const T* rr = recon + row * rstride;
       T* gr = grecon + row * rstride;
+      __builtin_assume(sub < nvec);   // every geometry gives a lane at least one vector: no zero-trip path
       for (int j0 = sub; j0 < nvec; j0 += G * U) {
         float xv[U][V], a[U][V], b[U][V];
         load_chunk<T, V, U, kNtNllFwd>(xr, j0, G, nvec, xv);
         load_chunk<T, V, U, kNtNllFwd>(rr, j0, G, nvec, a);
         if constexpr (NLL != VAE_NLL_BERNOULLI) load_chunk<T, V, U, kNtNllFwd>(rr + D, j0, G, nvec, b);
+        // take delivery of the epilogue's inputs HERE, where only loads are younger: vmcnt retires in order, so a
+        // wait for them behind the gradient stores is a wait for the acknowledgement of every one of those stores
+        asm volatile("" ::"v"(k), "v"(ad), "v"(m));
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int j = j0 + u * G;
@@ -259,8 +268,8 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_fused_kernel(
                 ga[i] *= cscale; gb[i] *= cscale;
               }
             }
-            store_vec<T, V>(gr + (int64_t)j * V, ga);
-            if constexpr (NLL != VAE_NLL_BERNOULLI) store_vec<T, V>(gr + D + (int64_t)j * V, gb);
+            store_vec<T, V>(nts, gr + (int64_t)j * V, ga);
+            if constexpr (NLL != VAE_NLL_BERNOULLI) store_vec<T, V>(nts, gr + D + (int64_t)j * V, gb);
           }
         }
       }
@@ -268,18 +277,13 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_fused_kernel(
     s = row_sum(s, G);
     if (row < B && sub == 0) {
       const float n = to_f32(from_f32<T>(s));
-      nll_out[row] = from_f32<T>(n);
-      const float k = kld ? to_f32(kld[row]) : 0.f;
-      const float ad = add ? to_f32(add[row]) : 0.f;
-      const float m = mi ? to_f32(mi[row]) : 0.f;
       const float e = to_f32(from_f32<T>(n + k));
       const float l = to_f32(from_f32<T>((n + ad + kl_beta * k) - m));
+      nll_out[row] = from_f32<T>(n);
       loss[row] = from_f32<T>(l);
       elbo[row] = from_f32<T>(e);
-      acc[0] += l; acc[1] += e; acc[2] += n; acc[3] += k; acc[4] += ad; acc[5] += m;
     }
   }
-  grid_reduce<6>(acc, ws, inv_count, means);
 }
 
 // buf *= (gmeans[0] + gmeans[1] + gmeans[2]) unless that sum is exactly 1 (then no memory is touched):
@@ -334,18 +338,19 @@ static int nll_fused_dispatch(const void* x, const void* recon, const void* kld,
                               float cscale, int64_t B, int64_t D, float kl_beta, float inv_count, hipStream_t stream) {
   constexpr int VN = VecOf<T>::n;
   const bool vec = (D % VN == 0) && aligned16(x) && aligned16(recon) && aligned16(grecon);
-  const RowGeom g = nll_geom(B, vec ? D / VN : D, kGridReduce, true);
+  const RowGeom g = nll_geom(B, vec ? D / VN : D, kGridStream, true);
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_fused_kernel<T, VN, NLL, U>), dim3(g.grid), dim3(kBlock), 0, stream,
                                          (const T*)x, (const T*)recon, (const T*)kld, (const T*)add, (const T*)mi,
-                                         (T*)nll, (T*)loss, (T*)elbo, workspace, inv_count, means, (T*)grecon, cscale, B,
-                                         (int)D, kl_beta, g.G, g.tiles));
+                                         (T*)nll, (T*)loss, (T*)elbo, (T*)grecon, cscale, B, (int)D, kl_beta, g.G,
+                                         g.tiles));
   } else {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_fused_kernel<T, 1, NLL, U>), dim3(g.grid), dim3(kBlock), 0, stream,
                                          (const T*)x, (const T*)recon, (const T*)kld, (const T*)add, (const T*)mi,
-                                         (T*)nll, (T*)loss, (T*)elbo, workspace, inv_count, means, (T*)grecon, cscale, B,
-                                         (int)D, kl_beta, g.G, g.tiles));
+                                         (T*)nll, (T*)loss, (T*)elbo, (T*)grecon, cscale, B, (int)D, kl_beta, g.G,
+                                         g.tiles));
   }
+  launch_rows_means<T>(loss, elbo, nll, kld, add, mi, workspace, inv_count, means, B, stream);
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 
@@ -374,19 +379,17 @@ static int nll_fwd_dispatch(const void* x, const void* recon, const void* kld, c
                             float kl_beta, float inv_count, hipStream_t stream) {
   constexpr int VN = VecOf<T>::n;
   const bool vec = (D % VN == 0) && aligned16(x) && aligned16(recon);
-  const RowGeom g = nll_geom(B, vec ? D / VN : D, kGridReduce);
-  float* partials = (loss && means) ? workspace : nullptr;
+  const RowGeom g = nll_geom(B, vec ? D / VN : D, kGridStream);
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_fwd_kernel<T, VN, NLL, U>), dim3(g.grid), dim3(kBlock), 0, stream,
                                          (const T*)x, (const T*)recon, (const T*)kld, (const T*)add, (const T*)mi,
-                                         (T*)nll, (T*)loss, (T*)elbo, partials, inv_count, means, B, (int)D, kl_beta, g.G,
-                                         g.tiles));
+                                         (T*)nll, (T*)loss, (T*)elbo, B, (int)D, kl_beta, g.G, g.tiles));
   } else {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_fwd_kernel<T, 1, NLL, U>), dim3(g.grid), dim3(kBlock), 0, stream,
                                          (const T*)x, (const T*)recon, (const T*)kld, (const T*)add, (const T*)mi,
-                                         (T*)nll, (T*)loss, (T*)elbo, partials, inv_count, means, B, (int)D, kl_beta, g.G,
-                                         g.tiles));
+                                         (T*)nll, (T*)loss, (T*)elbo, B, (int)D, kl_beta, g.G, g.tiles));
   }
+  if (loss && means) launch_rows_means<T>(loss, elbo, nll, kld, add, mi, workspace, inv_count, means, B, stream);
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(kBlock) void flow_bwd_kernel(const T* __restrict__ 
                                                          const float* __restrict__ gsum, T* __restrict__ gu,
                                                          int64_t B, int F, float scale, int G, int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * F * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = F / V;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void flow_bwd_kernel(const T* __restrict__ 
         if (j < nvec) {
 #pragma unroll
           for (int i = 0; i < V; ++i) x[k][i] *= c;
-          store_vec<T, V>(gu + row * F + (int64_t)j * V, x[k]);
+          store_vec<T, V>(nts, gu + row * F + (int64_t)j * V, x[k]);
         }
       }
     }

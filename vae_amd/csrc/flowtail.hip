@@ -52,6 +52,7 @@ __global__ __launch_bounds__(kBlock) void made_tail_fwd_kernel(
     T* __restrict__ u, const T* __restrict__ ld_in, T* __restrict__ ld_out, int64_t B, int F, int pre_tanh, int G,
     int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * F * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = F / V;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(kBlock) void made_tail_fwd_kernel(
               o[i] = (xv[k][i] - mv[k][i]) * exp_acc(-ai);
               s -= ai;
             }
-            store_vec<T, V>(u + row * F + (int64_t)j * V, o);
+            store_vec<T, V>(nts, u + row * F + (int64_t)j * V, o);
           }
         }
       }
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(kBlock) void made_tail_bwd_kernel(
     T* __restrict__ gx, T* __restrict__ gm, int64_t sgm, T* __restrict__ ga, int64_t sga, int64_t B, int F,
     int pre_tanh, int G, int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * F * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = F / V;
@@ -119,9 +121,9 @@ __global__ __launch_bounds__(kBlock) void made_tail_bwd_kernel(
             if (pre_tanh) d *= (1.0f - ai * ai);
             oa[i] = d;
           }
-          if (gx) store_vec<T, V>(gx + row * F + (int64_t)j * V, ox);
-          store_vec<T, V>(gm + row * sgm + (int64_t)j * V, om);
-          store_vec<T, V>(ga + row * sga + (int64_t)j * V, oa);
+          if (gx) store_vec<T, V>(nts, gx + row * F + (int64_t)j * V, ox);
+          store_vec<T, V>(nts, gm + row * sgm + (int64_t)j * V, om);
+          store_vec<T, V>(nts, ga + row * sga + (int64_t)j * V, oa);
         }
       }
     }
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(kBlock) void coupling_tail_fwd_kernel(
     const T* __restrict__ x, const T* __restrict__ s_raw, const T* __restrict__ t_raw, const float* __restrict__ mask,
     T* __restrict__ y, const T* __restrict__ ld_in, T* __restrict__ ld_out, int64_t B, int F, int G, int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * F * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = F / V;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void coupling_tail_fwd_kernel(
               o[i] = add_rn(s_raw ? mul_rn(xv[k][i], exp_acc(ls)) : xv[k][i], mul_rn(tv[k][i], inv));
               s += ls;
             }
-            store_vec<T, V>(y + row * F + (int64_t)j * V, o);
+            store_vec<T, V>(nts, y + row * F + (int64_t)j * V, o);
           }
         }
       }
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(kBlock) void coupling_tail_bwd_kernel(
     const T* __restrict__ gld, T* __restrict__ gx, T* __restrict__ gs, T* __restrict__ gt, int64_t B, int F, int G,
     int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * F * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = F / V;
@@ -210,9 +214,9 @@ __global__ __launch_bounds__(kBlock) void coupling_tail_bwd_kernel(
             ot[i] = g * inv;
           }
           const int64_t o = row * F + (int64_t)j * V;
-          if (gx) store_vec<T, V>(gx + o, ox);
-          if (gs) store_vec<T, V>(gs + o, os);
-          store_vec<T, V>(gt + o, ot);
+          if (gx) store_vec<T, V>(nts, gx + o, ox);
+          if (gs) store_vec<T, V>(nts, gs + o, os);
+          store_vec<T, V>(nts, gt + o, ot);
         }
       }
     }
@@ -464,6 +468,7 @@ __global__ __launch_bounds__(kBlock) void bn_apply_fwd_kernel(
     const float* __restrict__ shift, const float* __restrict__ ldc, T* __restrict__ y, const T* __restrict__ ld_in,
     T* __restrict__ ld_out, int64_t B, int F, int rev, int G, int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * F * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = F / V;
@@ -495,7 +500,7 @@ __global__ __launch_bounds__(kBlock) void bn_apply_fwd_kernel(
             const float v = (xv[k][i] - mu[k][i]) * sc[k][i] + sh[k][i];
             if (rev) o[V - 1 - i] = v; else o[i] = v;
           }
-          store_vec<T, V>(y + row * F + (int64_t)(rev ? nvec - 1 - j : j) * V, o);
+          store_vec<T, V>(nts, y + row * F + (int64_t)(rev ? nvec - 1 - j : j) * V, o);
         }
       }
     }
@@ -510,6 +515,7 @@ __global__ __launch_bounds__(kBlock) void bn_apply_bwd_kernel(
     const float* __restrict__ k1, const float* __restrict__ kk, T* __restrict__ gx, int64_t B, int F, int training,
     int rev, int G, int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * F * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = F / V;
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(kBlock) void bn_apply_bwd_kernel(
 #pragma unroll
           for (int i = 0; i < V; ++i)
             o[i] = training ? sc[k][i] * gv[k][i] - c1[k][i] - (xv[k][i] - mu[k][i]) * c2[k][i] : sc[k][i] * gv[k][i];
-          store_vec<T, V>(gx + row * F + (int64_t)j * V, o);
+          store_vec<T, V>(nts, gx + row * F + (int64_t)j * V, o);
         }
       }
     }

@@ -33,6 +33,7 @@ __global__ __launch_bounds__(kBlock) void gauss_fwd_kernel(
     int64_t z_stride, T* __restrict__ s_out, T* __restrict__ kl, float* __restrict__ ws, float mean_scale,
     float* __restrict__ means, int64_t B, int L, float eps_tol, int training, uint64_t seed, uint64_t offset, int64_t row0, int G, int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * L * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = L / V;
@@ -71,8 +72,8 @@ __global__ __launch_bounds__(kBlock) void gauss_fwd_kernel(
               acc[0] += m;
               acc[1] += si;
             }
-            if (z) store_vec<T, V>(z + row * z_stride + (int64_t)j * V, zz);
-            if (s_out) store_vec<T, V>(s_out + row * L + (int64_t)j * V, s[u]);
+            if (z) store_vec<T, V>(nts, z + row * z_stride + (int64_t)j * V, zz);
+            if (s_out) store_vec<T, V>(nts, s_out + row * L + (int64_t)j * V, s[u]);
           }
         }
       }
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(kBlock) void gauss_bwd_kernel(
     T* __restrict__ glogits, int64_t gl_stride, int64_t B, int L, float eps_tol, float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0,
     int G, int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * L * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = L / V;
@@ -127,8 +129,8 @@ __global__ __launch_bounds__(kBlock) void gauss_bwd_kernel(
             dmu[i] = gzi + gk * mu[u][i] + gm_mu;
             ds[i] = (use_e ? 0.5f * e[u][i] * gzi : 0.f) + (gs ? g2[u][i] : 0.f) + gk * (si - fast_rcp(si)) + gm_s;
           }
-          store_vec<T, V>(grow + (int64_t)j * V, dmu);
-          store_vec<T, V>(grow + L + (int64_t)j * V, ds);
+          store_vec<T, V>(nts, grow + (int64_t)j * V, dmu);
+          store_vec<T, V>(nts, grow + L + (int64_t)j * V, ds);
         }
       }
     }
@@ -191,6 +193,7 @@ __global__ __launch_bounds__(kBlock) void gauss_kl_bwd_kernel(
     int64_t sp_mu, const T* __restrict__ s_p, int64_t sp_s, const T* __restrict__ gkl, T* __restrict__ g_mu_q,
     T* __restrict__ g_s_q, T* __restrict__ g_mu_p, T* __restrict__ g_s_p, int64_t B, int L, int G, int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * L * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = L / V;
@@ -224,11 +227,11 @@ __global__ __launch_bounds__(kBlock) void gauss_kl_bwd_kernel(
         }
       }
       const int64_t o = row * L + (int64_t)j * V;
-      store_vec<T, V>(g_mu_q + o, o0);
-      store_vec<T, V>(g_s_q + o, o1);
+      store_vec<T, V>(nts, g_mu_q + o, o0);
+      store_vec<T, V>(nts, g_s_q + o, o1);
       if (mu_p && g_mu_p) {
-        store_vec<T, V>(g_mu_p + o, o2);
-        store_vec<T, V>(g_s_p + o, o3);
+        store_vec<T, V>(nts, g_mu_p + o, o2);
+        store_vec<T, V>(nts, g_s_p + o, o3);
       }
     }
   }

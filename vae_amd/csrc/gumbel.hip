@@ -29,6 +29,7 @@ __global__ __launch_bounds__(kBlock) void gumbel_fwd_kernel(
     int64_t y_stride, T* __restrict__ zh_out, int64_t zh_stride, T* __restrict__ lq_out, int64_t B, int K, float tau, uint64_t seed, uint64_t offset,
     int64_t row0, int G, int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * K * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = K / V;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void gumbel_fwd_kernel(
             float lq[V];
 #pragma unroll
             for (int i = 0; i < V; ++i) lq[i] = sub_rn(sub_rn(l[k][i], m1), lse);
-            store_vec<T, V>(lq_out + row * K + (int64_t)j * V, lq);
+            store_vec<T, V>(nts, lq_out + row * K + (int64_t)j * V, lq);
           }
         }
       }
@@ -143,9 +144,9 @@ __global__ __launch_bounds__(kBlock) void gumbel_fwd_kernel(
             zh[i] = add_rn(to_f32(from_f32<T>(sub_rn(h, x[k][i]))), x[k][i]);  // (h - y).detach() + y
             lq[i] = sub_rn(sub_rn(l[k][i], m1), lse);
           }
-          if (y_out) store_vec<T, V>(y_out + row * y_stride + (int64_t)j * V, x[k]);
-          if (zh_out) store_vec<T, V>(zh_out + row * zh_stride + (int64_t)j * V, zh);
-          if (want_lq) store_vec<T, V>(lq_out + row * K + (int64_t)j * V, lq);
+          if (y_out) store_vec<T, V>(nts, y_out + row * y_stride + (int64_t)j * V, x[k]);
+          if (zh_out) store_vec<T, V>(nts, zh_out + row * zh_stride + (int64_t)j * V, zh);
+          if (want_lq) store_vec<T, V>(nts, lq_out + row * K + (int64_t)j * V, lq);
         }
       }
     }
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(kBlock) void gumbel_bwd_kernel(
     const T* __restrict__ gzh, int64_t gzh_stride, const T* __restrict__ glq, T* __restrict__ glogits,
     int64_t gl_stride, int64_t B, int K, float tau, int G, int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * K * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = K / V;
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void gumbel_bwd_kernel(
             if (glq) v += gq[k][i] - exp_acc(q[k][i]) * sg;
             o[i] = v;
           }
-          store_vec<T, V>(glogits + row * gl_stride + (int64_t)j * V, o);
+          store_vec<T, V>(nts, glogits + row * gl_stride + (int64_t)j * V, o);
         }
       }
     }
@@ -263,6 +265,7 @@ __global__ __launch_bounds__(kBlock) void categorical_kl_kernel(
     const T* __restrict__ a, int64_t stride_a, const T* __restrict__ b, int64_t stride_b, const T* __restrict__ gkl,
     T* __restrict__ kl, T* __restrict__ ga, T* __restrict__ gb, int64_t B, int K, int G, int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * K * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = K / V;
@@ -299,8 +302,8 @@ __global__ __launch_bounds__(kBlock) void categorical_kl_kernel(
             oa[i] = gk * p * ((la[k][i] - lb[k][i]) - s);
             ob[i] = gk * (pb[k][i] - p);
           }
-          store_vec<T, V>(ga + row * K + (int64_t)j * V, oa);
-          if (gb) store_vec<T, V>(gb + row * K + (int64_t)j * V, ob);
+          store_vec<T, V>(nts, ga + row * K + (int64_t)j * V, oa);
+          if (gb) store_vec<T, V>(nts, gb + row * K + (int64_t)j * V, ob);
         }
       }
     }

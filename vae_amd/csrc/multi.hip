@@ -24,6 +24,7 @@ __global__ __launch_bounds__(kBlock) void gauss_multi_fwd_kernel(
     T* __restrict__ s_out, T* __restrict__ kl, float* __restrict__ ws, float mean_scale, float* __restrict__ means,
     int64_t B, int L, int S, float eps_tol, uint64_t seed, uint64_t offset, int64_t row0, int G, int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * L * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = L / V;
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(kBlock) void gauss_multi_fwd_kernel(
               acc[0] += m;
               acc[1] += si;
             }
-            if (s_out) store_vec<T, V>(s_out + row * L + (int64_t)j * V, s[u]);
+            if (s_out) store_vec<T, V>(nts, s_out + row * L + (int64_t)j * V, s[u]);
           }
         }
         for (int smp = 0; smp < S; ++smp) {
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void gauss_multi_fwd_kernel(
               float zz[V];
 #pragma unroll
               for (int i = 0; i < V; ++i) zz[i] = add_rn(to_f32(from_f32<T>(mul_rn(e[u][i], hs[u][i]))), mu[u][i]);
-              store_vec<T, V>(z + so + (int64_t)j * V, zz);
+              store_vec<T, V>(nts, z + so + (int64_t)j * V, zz);
             }
           }
         }
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(kBlock) void gauss_multi_bwd_kernel(
     int64_t B, int L, int S, float eps_tol, float mean_scale, uint64_t seed, uint64_t offset, int64_t row0, int G,
     int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * L * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = L / V;
@@ -139,8 +141,8 @@ __global__ __launch_bounds__(kBlock) void gauss_multi_bwd_kernel(
             dmu[i] = am[u][i] + gk * mu[u][i] + gm_mu;
             ds[i] = 0.5f * as[u][i] + (gs ? g2[u][i] : 0.f) + gk * (si - fast_rcp(si)) + gm_s;
           }
-          store_vec<T, V>(grow + (int64_t)j * V, dmu);
-          store_vec<T, V>(grow + L + (int64_t)j * V, ds);
+          store_vec<T, V>(nts, grow + (int64_t)j * V, dmu);
+          store_vec<T, V>(nts, grow + L + (int64_t)j * V, ds);
         }
       }
     }
@@ -165,20 +167,24 @@ __device__ __forceinline__ void* pick(const PtrPack& k, int s) {
 template <typename T, int V, int NLL, int U>
 __global__ __launch_bounds__(kBlock) void nll_multi_fwd_kernel(
     const T* __restrict__ x, PtrPack recons, int S, const T* __restrict__ kld, const T* __restrict__ add,
-    const T* __restrict__ mi, T* __restrict__ nll_out, T* __restrict__ loss, T* __restrict__ elbo,
-    float* __restrict__ ws, float inv_count, float* __restrict__ means, int64_t B, int D, float kl_beta, int G,
-    int64_t tiles) {
+    const T* __restrict__ mi, T* __restrict__ nll_out, T* __restrict__ loss, T* __restrict__ elbo, int64_t B, int D,
+    float kl_beta, int G, int64_t tiles) {
   const int rpb = kBlock / G;
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = D / V;
   const int64_t rstride = (NLL == VAE_NLL_BERNOULLI) ? (int64_t)D : 2 * (int64_t)D;
   const float inv_s = 1.0f / (float)S;
-  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
     const int64_t row = t * rpb + rloc;
     float s = 0.f;
+    float k = 0.f, ad = 0.f, m = 0.f;   // requested with the row (see nll_elbo_fused_kernel)
     if (row < B) {
+      if (loss) {
+        if (kld) k = to_f32(kld[row]);
+        if (add) ad = to_f32(add[row]);
+        if (mi) m = to_f32(mi[row]);
+      }
       const T* xr = x + row * D;
       for (int j0 = sub; j0 < nvec; j0 += G * U) {
         float xv[U][V];
@@ -207,18 +213,13 @@ __global__ __launch_bounds__(kBlock) void nll_multi_fwd_kernel(
       const float n = to_f32(from_f32<T>(s * inv_s));
       nll_out[row] = from_f32<T>(n);
       if (loss) {
-        const float k = kld ? to_f32(kld[row]) : 0.f;
-        const float ad = add ? to_f32(add[row]) : 0.f;
-        const float m = mi ? to_f32(mi[row]) : 0.f;
         const float e = to_f32(from_f32<T>(n + k));
         const float l = to_f32(from_f32<T>((n + ad + kl_beta * k) - m));
         loss[row] = from_f32<T>(l);
         elbo[row] = from_f32<T>(e);
-        acc[0] += l; acc[1] += e; acc[2] += n; acc[3] += k; acc[4] += ad; acc[5] += m;
       }
     }
   }
-  if (ws) grid_reduce<6>(acc, ws, inv_count, means);
 }
 
 template <typename T, int V, int NLL, int U>
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(kBlock) void nll_multi_bwd_kernel(
     T* __restrict__ gadd, T* __restrict__ gmi, int64_t B, int D, float kl_beta, float inv_count, int G,
     int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * D * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = D / V;
@@ -274,8 +276,8 @@ __global__ __launch_bounds__(kBlock) void nll_multi_bwd_kernel(
                 ga[i] *= c; gb[i] *= c;
               }
             }
-            store_vec<T, V>(gr + (int64_t)j * V, ga);
-            if constexpr (NLL != VAE_NLL_BERNOULLI) store_vec<T, V>(gr + D + (int64_t)j * V, gb);
+            store_vec<T, V>(nts, gr + (int64_t)j * V, ga);
+            if constexpr (NLL != VAE_NLL_BERNOULLI) store_vec<T, V>(nts, gr + D + (int64_t)j * V, gb);
           }
         }
       }
@@ -346,19 +348,17 @@ static int nll_multi_fwd_dispatch(const void* x, const PtrPack& rp, bool al, int
                                   int64_t B, int64_t D, float kl_beta, float inv_count, hipStream_t st) {
   constexpr int VN = VecOf<T>::n;
   const bool vec = (D % VN == 0) && aligned16(x) && al;
-  const RowGeom g = nll_geom(B, vec ? D / VN : D, kGridReduce);
-  float* partials = (loss && means) ? ws : nullptr;
+  const RowGeom g = nll_geom(B, vec ? D / VN : D, kGridStream);
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_multi_fwd_kernel<T, VN, NLL, U>), dim3(g.grid), dim3(kBlock), 0, st,
                                          (const T*)x, rp, S, (const T*)kld, (const T*)add, (const T*)mi, (T*)nll,
-                                         (T*)loss, (T*)elbo, partials, inv_count, means, B, (int)D, kl_beta, g.G,
-                                         g.tiles));
+                                         (T*)loss, (T*)elbo, B, (int)D, kl_beta, g.G, g.tiles));
   } else {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_multi_fwd_kernel<T, 1, NLL, U>), dim3(g.grid), dim3(kBlock), 0, st,
                                          (const T*)x, rp, S, (const T*)kld, (const T*)add, (const T*)mi, (T*)nll,
-                                         (T*)loss, (T*)elbo, partials, inv_count, means, B, (int)D, kl_beta, g.G,
-                                         g.tiles));
+                                         (T*)loss, (T*)elbo, B, (int)D, kl_beta, g.G, g.tiles));
   }
+  if (loss && means) launch_rows_means<T>(loss, elbo, nll, kld, add, mi, ws, inv_count, means, B, st);
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 

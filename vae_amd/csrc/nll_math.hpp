@@ -90,4 +90,70 @@ inline RowGeom nll_geom(int64_t B, int64_t vecs_per_row, int64_t max_grid, bool 
   return g;
 }
 
+// The six batch means (abstract_vae.py:381-387) from the per-sample vectors the NLL + ELBO forward has just written
+// (loss, elbo, nll) and read (kld, add, mi): a closing launch of <= 64 blocks behind the streaming kernel.  The
+// streaming kernels then carry no reduction at all -- no accumulators, no barrier, no ticket -- and run one row tile
+// per block, handed out by the hardware dispatcher as blocks retire.  Measured r02 in the bench.py step (B = 65536,
+// 784 px, one-pass NLL, event-bracketed): streaming kernel alone 104.3 us; + this launch 111.5 us; against 115.3 us
+// for <= 1024 persistent blocks with grid_reduce inside the kernel, 119-121 us for one tile per block with a
+// per-block or two-level ticket inside the kernel (the closing chain -- store drain, ticket(s), acquire, partial
+// loads -- is 8-10 dependent round trips of ~1 us on a loaded chip; a static partition loses ~7 us to the dynamic
+// hand-out whatever its grid: scripts/membench.hip).  Thread i adds vectors i, i + grid*256, ... in order (double);
+// blocks in block order: deterministic for a given B.
+template <typename T, int V>
+__global__ __launch_bounds__(kBlock) void elbo_rows_means_kernel(const T* __restrict__ loss, const T* __restrict__ elbo,
+                                                                 const T* __restrict__ nll, const T* __restrict__ kld,
+                                                                 const T* __restrict__ add, const T* __restrict__ mi,
+                                                                 float* __restrict__ ws, float inv_count,
+                                                                 float* __restrict__ means, int64_t B) {
+  double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  const int64_t nvec = B / V;   // whole vectors; the B % V rows of the tail go to the first threads of block 0
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < nvec; j += (int64_t)gridDim.x * kBlock) {
+    float a[6][V];
+    load_vec<T, V, false>(loss + j * V, a[0]);
+    load_vec<T, V, false>(elbo + j * V, a[1]);
+    load_vec<T, V, false>(nll + j * V, a[2]);
+    if (kld) load_vec<T, V, false>(kld + j * V, a[3]);
+    if (add) load_vec<T, V, false>(add + j * V, a[4]);
+    if (mi) load_vec<T, V, false>(mi + j * V, a[5]);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      v[0] += (double)a[0][i];
+      v[1] += (double)a[1][i];
+      v[2] += (double)a[2][i];
+      if (kld) v[3] += (double)a[3][i];
+      if (add) v[4] += (double)a[4][i];
+      if (mi) v[5] += (double)a[5][i];
+    }
+  }
+  if (blockIdx.x == 0 && (int64_t)threadIdx.x < B - nvec * V) {
+    const int64_t row = nvec * V + threadIdx.x;
+    v[0] += (double)to_f32(loss[row]);
+    v[1] += (double)to_f32(elbo[row]);
+    v[2] += (double)to_f32(nll[row]);
+    if (kld) v[3] += (double)to_f32(kld[row]);
+    if (add) v[4] += (double)to_f32(add[row]);
+    if (mi) v[5] += (double)to_f32(mi[row]);
+  }
+  close_block_sums_d<6>(v, ws, inv_count, means);
+}
+
+template <typename T>
+inline void launch_rows_means(const void* loss, const void* elbo, const void* nll, const void* kld, const void* add,
+                              const void* mi, float* ws, float inv_count, float* means, int64_t B,
+                              hipStream_t stream) {
+  constexpr int VN = VecOf<T>::n;
+  const bool vec = aligned16(loss) && aligned16(elbo) && aligned16(nll) && (!kld || aligned16(kld)) &&
+                   (!add || aligned16(add)) && (!mi || aligned16(mi));
+  const int64_t items = vec ? (B + VN - 1) / VN : B;
+  int64_t blocks = (items + kBlock - 1) / kBlock;
+  const int grid = (int)(blocks < 64 ? blocks : 64);
+  if (vec)
+    hipLaunchKernelGGL((elbo_rows_means_kernel<T, VN>), dim3(grid), dim3(kBlock), 0, stream, (const T*)loss, (const T*)elbo,
+                       (const T*)nll, (const T*)kld, (const T*)add, (const T*)mi, ws, inv_count, means, B);
+  else
+    hipLaunchKernelGGL((elbo_rows_means_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, stream, (const T*)loss, (const T*)elbo,
+                     (const T*)nll, (const T*)kld, (const T*)add, (const T*)mi, ws, inv_count, means, B);
+}
+
 }  // namespace vae

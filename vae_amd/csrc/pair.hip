@@ -26,6 +26,7 @@ __global__ __launch_bounds__(kBlock) void gauss_pair_fwd_kernel(
     T* __restrict__ kl_prior, float* __restrict__ ws, float mean_scale, float* __restrict__ means, int64_t B, int L,
     float eps_tol, int training, uint64_t seed, uint64_t offset, int64_t row0, int G, int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * L * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = L / V;
@@ -78,13 +79,13 @@ __global__ __launch_bounds__(kBlock) void gauss_pair_fwd_kernel(
             }
             const int64_t o = row * L + (int64_t)j * V;
             if (training) {
-              store_vec<T, V>(z_q + o, zq);
-              store_vec<T, V>(z_p + o, zp);
+              store_vec<T, V>(nts, z_q + o, zq);
+              store_vec<T, V>(nts, z_p + o, zp);
             }
-            if (lv_q) store_vec<T, V>(lv_q + o, sq[u]);
-            if (lv_p) store_vec<T, V>(lv_p + o, eq[u]);
-            store_vec<T, V>(clamped + row * 2 * (int64_t)L + (int64_t)j * V, mp[u]);
-            store_vec<T, V>(clamped + row * 2 * (int64_t)L + L + (int64_t)j * V, sp[u]);
+            if (lv_q) store_vec<T, V>(nts, lv_q + o, sq[u]);
+            if (lv_p) store_vec<T, V>(nts, lv_p + o, eq[u]);
+            store_vec<T, V>(nts, clamped + row * 2 * (int64_t)L + (int64_t)j * V, mp[u]);
+            store_vec<T, V>(nts, clamped + row * 2 * (int64_t)L + L + (int64_t)j * V, sp[u]);
           }
         }
       }
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(kBlock) void gauss_pair_bwd_kernel(
     const float* __restrict__ gmeans, T* __restrict__ g_enc, T* __restrict__ g_pri, int64_t B, int L, float eps_tol,
     float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0, int G, int64_t tiles) {
   const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * L * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = L / V;
@@ -168,10 +170,10 @@ __global__ __launch_bounds__(kBlock) void gauss_pair_bwd_kernel(
                               g0 * (lp - ip) + gm[3] + (glv_p ? x2[i] : 0.f);
             osp[i] = (glp + (gclamped ? c2[i] : 0.f)) * cl * (1.0f - cl);
           }
-          store_vec<T, V>(g_enc + row * 2 * (int64_t)L + (int64_t)j * V, omq);
-          store_vec<T, V>(g_enc + row * 2 * (int64_t)L + L + (int64_t)j * V, osq);
-          store_vec<T, V>(g_pri + row * 2 * (int64_t)L + (int64_t)j * V, omp);
-          store_vec<T, V>(g_pri + row * 2 * (int64_t)L + L + (int64_t)j * V, osp);
+          store_vec<T, V>(nts, g_enc + row * 2 * (int64_t)L + (int64_t)j * V, omq);
+          store_vec<T, V>(nts, g_enc + row * 2 * (int64_t)L + L + (int64_t)j * V, osq);
+          store_vec<T, V>(nts, g_pri + row * 2 * (int64_t)L + (int64_t)j * V, omp);
+          store_vec<T, V>(nts, g_pri + row * 2 * (int64_t)L + L + (int64_t)j * V, osp);
         }
       }
     }
