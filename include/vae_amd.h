@@ -230,6 +230,20 @@ int vae_nll_elbo_fused(const void* x, const void* recon, int nll_type, const voi
                        float kl_beta, float inv_count, float grad_scale, void* nll, void* loss, void* elbo, float* means,
                        float* workspace, void* grecon, int64_t B, int64_t D, int dtype, vae_stream_t stream);
 int vae_nll_fused_grad_finish(void* grecon, const float* gmeans, int64_t n, int dtype, vae_stream_t stream);
+/* vae_nll_elbo_fused for callers that cannot allocate or keep a workspace (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc): the same kernels, with the scratch they need -- the closing
+ * launch's arrival counters and block partials, vae_workspace_bytes() = 68 KiB -- in a file-scope __device__ array
+ * of the library instead of a caller buffer.  No counterpart in the reference.  The call allocates and frees
+ * nothing; every GPU the library is used on holds its own copy of the array until the process ends.  Arguments as
+ * vae_nll_elbo_fused without `workspace`; the device that owns `stream` must be the current device.  B up to
+ * VAE_STATIC_MAX_ROWS, beyond it VAE_ERR_ARG.  All calls on one GPU share that GPU's array: calls that overlap in
+ * time on one GPU (two streams, two threads) race on it -- serialise them, or use vae_nll_elbo_fused with a workspace
+ * per stream.                                                                                          */
+#define VAE_STATIC_MAX_ROWS (1 << 24)
+int vae_nll_elbo_fused_static(const void* x, const void* recon, int nll_type, const void* kld, const void* add,
+                              const void* mi, float kl_beta, float inv_count, float grad_scale, void* nll, void* loss,
+                              void* elbo, float* means, void* grecon, int64_t B, int64_t D, int dtype,
+                              vae_stream_t stream);
 /* Both of the above in one launch, for the step whose only upstream gradients are those of the six means
  * (loss['loss_mean'].backward(), abstract_vae.py:381): the conditional rescale of the n stored gradient values
  * and gkld / gadd / gmi [B] (each may be NULL) = what vae_elbo_combine_bwd writes with gloss = gelbo = NULL.

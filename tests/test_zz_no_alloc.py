@@ -1,0 +1,55 @@
+"""The allocation-free entry point (vae_nll_elbo_fused_static: its scratch is a __device__ array of the library)
+against vae_nll_elbo_fused with a caller workspace, through the C ABI: every output bit for bit (same kernels, same
+summation order), on two calls in a row, the second with a smaller input -- the array keeps the first call's
+contents."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _run(name, x, recon, kld, nll_type, dtype_code, with_ws):
+    from vae_amd import _lib
+    from vae_amd._lib import call, ptr
+    B, D = x.shape
+    rw = recon.shape[1]
+    mk = lambda *s: torch.full(s, float('nan'), dtype=x.dtype, device=DEV)
+    nll, loss, elbo, grecon = mk(B), mk(B), mk(B), mk(B, rw)
+    means = torch.full((6,), float('nan'), device=DEV)
+    st = _lib.stream_ptr(torch.device(DEV))
+    args = [ptr(x), ptr(recon), nll_type, ptr(kld), None, None, 0.7, 1.0 / B, 1.0, ptr(nll), ptr(loss), ptr(elbo),
+            ptr(means)]
+    if with_ws:
+        args.append(ptr(_lib.workspace(torch.device(DEV))))
+    call(name, *args, ptr(grecon), B, D, dtype_code, st)
+    torch.cuda.synchronize()
+    return nll, loss, elbo, means, grecon
+
+
+@pytest.mark.parametrize('nll_type,dtype', [(0, torch.float32), (2, torch.float32), (0, torch.bfloat16)])
+def test_static_scratch_matches_workspace_entry_point(nll_type, dtype):
+    code = {torch.float32: 0, torch.bfloat16: 1}[dtype]
+    g = torch.Generator(device=DEV).manual_seed(7 + nll_type)
+    # a big call first, then a smaller one: stale partials / counters of the first must not leak into the second
+    for B, D in ((4099, 784), (37, 784), (1, 16)):
+        x = torch.rand(B, D, generator=g, device=DEV).to(dtype)
+        recon = torch.randn(B, D if nll_type == 0 else 2 * D, generator=g, device=DEV).to(dtype)
+        kld = torch.rand(B, generator=g, device=DEV).to(dtype)
+        ref = _run('vae_nll_elbo_fused', x, recon, kld, nll_type, code, True)
+        got = _run('vae_nll_elbo_fused_static', x, recon, kld, nll_type, code, False)
+        for r, o, what in zip(ref, got, ('nll', 'loss', 'elbo', 'means', 'grecon')):
+            assert not bool(torch.isnan(o.float()).any()), what
+            assert torch.equal(r, o), (what, B, D)
+
+
+def test_static_scratch_rejects_oversize():
+    from vae_amd import _lib
+    lib = _lib.load()
+    x = torch.zeros(4, 8, device=DEV)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = lib.vae_nll_elbo_fused_static(p(x), p(x), 0, None, None, None, 1.0, 1.0, 1.0, p(x), p(x), p(x), p(x), p(x),
+                                       (1 << 24) + 1, 8, 0, None)
+    assert rc == _lib.VAE_ERR_ARG

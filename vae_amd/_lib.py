@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the CDLL below, see module 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VAE_AMD_LIB') or os.path.join(_HERE, 'libvae_amd.so')  # env override: tuning builds only
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 VAE_OK, VAE_ERR_ARG, VAE_ERR_LAUNCH = 0, 1, 2
 VAE_F32, VAE_BF16, VAE_F16 = 0, 1, 2
@@ -56,6 +56,7 @@ SIGNATURES = {
     'vae_nll_elbo_bwd': [_p, _p, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i64, _i, _p],
     'vae_nll_elbo_fused': [_p, _p, _i, _p, _p, _p, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
     'vae_nll_fused_grad_finish': [_p, _p, _i64, _i, _p],
+    'vae_nll_elbo_fused_static': [_p, _p, _i, _p, _p, _p, _f, _f, _f, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
     'vae_nll_fused_backward': [_p, _i64, _p, _f, _f, _p, _p, _p, _i64, _i, _p],
     'vae_elbo_combine_fwd': [_p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i, _p],
     'vae_elbo_combine_bwd': [_p, _p, _p, _f, _f, _p, _p, _p, _p, _i64, _i, _p],

@@ -14,6 +14,8 @@
 // writes 12 bytes; the backward reads the same and writes 4D or 8D.  A row is
 // owned by G lanes (G <= 64: shuffles only) or by the whole block (G = 256: wave
 // shuffles, then LDS across the four waves) when rows are long and few.
+#include <mutex>
+
 #include "common.hpp"
 #include "nll_math.hpp"
 #include "../../include/vae_amd.h"
@@ -452,6 +454,34 @@ static int nll_bwd_type(int nll_type, const void* x, const void* recon, const vo
 
 }  // namespace vae
 
+// ---------------------------------------------------------------------------
+// Scratch for vae_nll_elbo_fused_static: what `workspace` is to the other entry points (the closing launch's
+// arrival counter and block partials), held by the code object instead of the caller.  Each GPU the library runs
+// on has its own copy at its own address; `scratch` itself is a host-side stand-in for the symbol, never an address
+// to hand to a kernel -- host code uses the pointer hipGetSymbolAddress returned for the current device.
+// ---------------------------------------------------------------------------
+static __device__ __align__(256) float scratch[vae::kWorkspaceFloats];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+float* g_scratch_ptr[kMaxDevices];   // per device, filled on that device's first call
+
+// The current device's copy of `scratch` (looked up once per device, with that device current).
+int scratch_for_current_device(float** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return VAE_ERR_LAUNCH;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return VAE_ERR_LAUNCH;
+    g_scratch_ptr[dev] = static_cast<float*>(p);
+  }
+  *out = g_scratch_ptr[dev];
+  return VAE_OK;
+}
+}  // namespace
+
 using namespace vae;
 
 extern "C" {
@@ -514,6 +544,22 @@ int vae_nll_elbo_fused(const void* x, const void* recon, int nll_type, const voi
     return nll_fused_type<f16_t>(nll_type, x, recon, kld, add, mi, nll, loss, elbo, means, workspace, grecon, cscale,
                                   B, D, kl_beta, inv_count, st);
   return VAE_ERR_ARG;
+}
+
+int vae_nll_elbo_fused_static(const void* x, const void* recon, int nll_type, const void* kld, const void* add,
+                              const void* mi, float kl_beta, float inv_count, float grad_scale, void* nll, void* loss,
+                              void* elbo, float* means, void* grecon, int64_t B, int64_t D, int dtype,
+                              vae_stream_t stream) {
+  if (B < 0 || B > VAE_STATIC_MAX_ROWS || D <= 0 || D > VAE_MAX_ROW) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  float* ws = nullptr;
+  const int rc = scratch_for_current_device(&ws);
+  if (rc != VAE_OK) return rc;
+  // The array keeps the last call's contents: the arrival counters must read zero when the closing launch starts
+  // (a completed call leaves them at zero; one that was cut short need not).
+  if (hipMemsetAsync(ws, 0, 1024 * sizeof(float), (hipStream_t)stream) != hipSuccess) return VAE_ERR_LAUNCH;
+  return vae_nll_elbo_fused(x, recon, nll_type, kld, add, mi, kl_beta, inv_count, grad_scale, nll, loss, elbo, means,
+                            ws, grecon, B, D, dtype, stream);
 }
 
 int vae_nll_fused_grad_finish(void* grecon, const float* gmeans, int64_t n, int dtype, vae_stream_t stream) {
