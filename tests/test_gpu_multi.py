@@ -206,3 +206,28 @@ def test_nll_multi_rejects_cpu_and_bad_shapes():
         F_.nll_multi_elbo(torch.zeros(2, 4), [torch.zeros(2, 4)], 'bernoulli')
     with pytest.raises(ValueError):
         F_.nll_multi_elbo(torch.zeros(2, 4, device=DEV), [torch.zeros(2, 5, device=DEV)], 'bernoulli')
+
+
+@pytest.mark.parametrize('dtype,rtol', [(torch.float16, 4e-3), (torch.bfloat16, 2e-2)])
+def test_nll_multi_more_than_max_samples_16bit(dtype, rtol):
+    """S > VAE_MAX_SAMPLES in a 16-bit element type: group launches + functional.elbo_combine, whose backward round 1
+    dispatched as bf16 whatever the dtype (VERDICT r01 weak #2)."""
+    from vae_amd import functional as F_
+    torch.manual_seed(3)
+    B, D, S = 64, 96, 11
+    x = (torch.rand(B, D) < 0.3).to(dtype)
+    recons = [(torch.randn(B, D) * 1.5).to(dtype) for _ in range(S)]
+    kld = (torch.rand(B) * 4).to(dtype)
+    r0 = [r.float().requires_grad_(True) for r in recons]
+    k0 = kld.float().requires_grad_(True)
+    d0 = O.loss_function(O.nll_multi(x.float(), r0, 'bernoulli'), k0, 0.7)
+    g0 = torch.autograd.grad(d0['loss_mean'] + 0.5 * d0['elbo_mean'], r0 + [k0])
+    r1 = [r.to(DEV).requires_grad_(True) for r in recons]
+    k1 = kld.to(DEV).requires_grad_(True)
+    n1, loss, elbo, means = F_.nll_multi_elbo(x.to(DEV), r1, 'bernoulli', kld=k1, kl_beta=0.7)
+    close(loss, d0['loss'], rtol=rtol, atol=rtol)
+    close(means[0], d0['loss_mean'], rtol=rtol, atol=rtol)
+    g1 = torch.autograd.grad(means[0] + 0.5 * means[1], r1 + [k1])
+    for a, b in zip(g1, g0):
+        assert a.dtype == dtype
+        close(a, b, rtol=rtol, atol=rtol * float(b.abs().max()))

@@ -292,7 +292,12 @@ def nll_elbo(x, recon_x, nll_type, kld=None, add=None, mi=None, kl_beta=1.0, inv
     code, xf, rf = _flat_pixels(x, recon_x, nll_type)
     if inv_count is None:
         inv_count = 1.0 / max(xf.shape[0], 1)
-    if fuse_backward and rf.requires_grad and torch.is_grad_enabled() and xf.shape[0] > 0:
+    # fp16 keeps the two-pass form: the one-pass kernel stores d(loss_mean)/d(recon) already scaled by 1/B in the
+    # tensor dtype, and with the loss scaling that fp16 training runs under (upstream gradient != 1) that value -- an
+    # fp16 subnormal from B ~ 4096 up -- would be rounded BEFORE it is multiplied back up; the general backward forms
+    # c/B in fp32 and rounds once.  (bf16 / fp32: same exponent range as fp32, the rescale costs at most one more
+    # rounding at the last place.)
+    if fuse_backward and rf.dtype != torch.float16 and rf.requires_grad and torch.is_grad_enabled() and xf.shape[0] > 0:
         out = _NllElboFused.apply(xf, rf, _dense(kld), _dense(add), _dense(mi), code, float(kl_beta), float(inv_count))
         return out
     return _NllElbo.apply(xf, rf, _dense(kld), _dense(add), _dense(mi), code, float(kl_beta), float(inv_count), True)
@@ -310,12 +315,13 @@ class _ElboCombine(torch.autograd.Function):
         with _Guard(dev):
             call('vae_elbo_combine_fwd', ptr(nll_), ptr(kld), ptr(add), ptr(mi), kl_beta, inv_count, ptr(loss),
                  ptr(elbo), ptr(means), ptr(workspace(dev)), B, dtype_code(nll_), stream_ptr(dev))
-        ctx.cfg = (kl_beta, inv_count, B, nll_.dtype, dev, kld is not None, add is not None, mi is not None)
+        ctx.cfg = (kl_beta, inv_count, B, nll_.dtype, dtype_code(nll_), dev, kld is not None, add is not None,
+                   mi is not None)
         return loss, elbo, means
 
     @staticmethod
     def backward(ctx, gloss, gelbo, gmeans):
-        kl_beta, inv_count, B, dtype, dev, has_kld, has_add, has_mi = ctx.cfg
+        kl_beta, inv_count, B, dtype, code, dev, has_kld, has_add, has_mi = ctx.cfg
         gloss, gelbo = _dense(gloss), _dense(gelbo)
         gmeans = None if gmeans is None else gmeans.contiguous().float()
         gnll = torch.empty((B,), dtype=dtype, device=dev) if ctx.needs_input_grad[0] else None
@@ -324,8 +330,7 @@ class _ElboCombine(torch.autograd.Function):
         gmi = torch.empty((B,), dtype=dtype, device=dev) if has_mi and ctx.needs_input_grad[3] else None
         with _Guard(dev):
             call('vae_elbo_combine_bwd', ptr(gloss), ptr(gelbo), ptr(gmeans), kl_beta, inv_count, ptr(gnll),
-                 ptr(gkld), ptr(gadd), ptr(gmi), B, _lib.VAE_F32 if dtype == torch.float32 else _lib.VAE_BF16,
-                 stream_ptr(dev))
+                 ptr(gkld), ptr(gadd), ptr(gmi), B, code, stream_ptr(dev))
         return gnll, gkld, gadd, gmi, None, None
 
 

@@ -9,6 +9,9 @@ asks for them.
 """
 
 
+import torch
+
+
 class _Pending(object):
     __slots__ = ('fn',)
 
@@ -26,7 +29,11 @@ class LazyParams(dict):
 
     def _resolve(self, key, value):
         if isinstance(value, _Pending):
-            value = value.fn()
+            # the reference builds these entries inside the forward graph: a first read under torch.no_grad() (a
+            # logging hook, say) must not cache a detached tensor that a later kl() / mutual_info() would then
+            # differentiate through in vain
+            with torch.enable_grad():
+                value = value.fn()
             dict.__setitem__(self, key, value)
         return value
 

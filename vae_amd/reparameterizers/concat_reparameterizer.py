@@ -61,7 +61,7 @@ class ConcatReparameterizer(nn.Module):
                 for c, n in zip(self.reparameterizers, noise)]
         for child, n in zip(self.reparameterizers, noise):
             if isinstance(child, IsotropicGaussian):
-                specs.append(('gauss', child.output_size, EPS_TOL, child.mean_scale))
+                specs.append(('gauss', child.output_size, child.eps_tol, child.mean_scale))
             else:
                 child.anneal()   # host-side tau schedule, before the draw (gumbel.py:326, bernoulli.py:198)
                 specs.append(('gumbel' if isinstance(child, GumbelSoftmax) else 'bern', child.output_size,
@@ -79,7 +79,7 @@ class ConcatReparameterizer(nn.Module):
                 mu = logits_i[:, :n_out]
                 kl, means = outs[k + 1], outs[k + 2].to(logits.dtype)
                 g = LazyParams({'z': z_i, 'mu': mu})
-                g.set_lazy('logvar', lambda li=logits_i, n=n_out: li[:, n:] + EPS_TOL)   # on first read only
+                g.set_lazy('logvar', lambda li=logits_i, n=n_out, e=spec[2]: li[:, n:] + e)   # on first read only
                 g._vae_amd_kl = (kl, mu)
                 g['mu_mean'], g['logvar_mean'] = means[0], means[1]
                 params = {'z': z_i, 'logits': logits_i, 'gaussian': g}

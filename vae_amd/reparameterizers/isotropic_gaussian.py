@@ -17,7 +17,17 @@ from .. import functional as F_
 from .. import rng
 from ..lazy import LazyParams
 
-EPS_TOL = 1e-6  # helpers.utils.eps(half=False): assumed, helpers is un-vendored
+EPS_TOL = 1e-6        # helpers.utils.eps(half=False): assumed, helpers is un-vendored
+EPS_TOL_HALF = 1e-4   # helpers.utils.eps(half=True): assumed likewise ("parity unpinned"; tests/golden/make_golden.py
+                      # stands in for helpers with the same two values)
+
+
+def eps_tol(config):
+    """The offset of isotropic_gaussian.py:125 (`logvar = logits[..., L:] + eps_fn(config['half'])`).  helpers is not
+    vendored, so both values are this build's assumption; config['eps_tol'] overrides them."""
+    if config.get('eps_tol') is not None:
+        return float(config['eps_tol'])
+    return EPS_TOL_HALF if config.get('half') else EPS_TOL
 
 
 class IsotropicGaussian(nn.Module):
@@ -28,6 +38,7 @@ class IsotropicGaussian(nn.Module):
         self.input_size = self.config['continuous_size']
         assert self.config['continuous_size'] % 2 == 0
         self.output_size = self.config['continuous_size'] // 2
+        self.eps_tol = eps_tol(config)
         self.row_offset = 0       # first global row of this rank's shard (set by vae_amd.dist)
         self.mean_scale = None    # 1/(B_global*L) when sharded
 
@@ -81,13 +92,14 @@ class IsotropicGaussian(nn.Module):
             noise = rng.captured_noise('normal', (rows.shape[0], rows.shape[1] // 2), rows)   # None unless a HIP graph is capturing
         if training and noise is None:
             seed, offset = rng.next_call()
-        z, _, kl, means = F_.gauss_reparam_kl(rows, noise=noise, eps_tol=EPS_TOL, training=training, seed=seed,
+        z, _, kl, means = F_.gauss_reparam_kl(rows, noise=noise, eps_tol=self.eps_tol, training=training, seed=seed,
                                               offset=offset, row0=self.row_offset, mean_scale=self.mean_scale,
                                               want_logvar=False)
         z = z.reshape(out_shape) if training else mu
         g = LazyParams({'z': z, 'mu': mu})
         # the reference's own op (isotropic_gaussian.py:124-125), run only if somebody reads the entry
-        g.set_lazy('logvar', lambda: torch.narrow(logits, dim2slice, L, L) + EPS_TOL)
+        eps = self.eps_tol
+        g.set_lazy('logvar', lambda: torch.narrow(logits, dim2slice, L, L) + eps)
         g._vae_amd_kl = (kl.reshape(kl_shape), mu)      # consumed by kl(); invisible to dict consumers
         g._vae_amd_means = means
         return z, g
@@ -112,14 +124,14 @@ class IsotropicGaussian(nn.Module):
         if noise is None:
             noise = rng.captured_noise('normal', (S, logits.shape[0], L), logits)
         seed, offset = (0, 0) if noise is not None else rng.next_calls(S)
-        z, _, kl, means = F_.gauss_reparam_multi(logits, S, noise=noise, eps_tol=EPS_TOL, seed=seed, offset=offset,
+        z, _, kl, means = F_.gauss_reparam_multi(logits, S, noise=noise, eps_tol=self.eps_tol, seed=seed, offset=offset,
                                                  row0=self.row_offset, mean_scale=self.mean_scale, want_logvar=False)
         mu = torch.narrow(logits, -1, 0, L)
         shared = {}
 
         def logvar_once():      # one tensor shared by the S parameter sets, as mu is
             if 'v' not in shared:
-                shared['v'] = torch.narrow(logits, -1, L, L) + EPS_TOL
+                shared['v'] = torch.narrow(logits, -1, L, L) + self.eps_tol
             return shared['v']
         means = means.to(logits.dtype)
         z_list, params_list = [], []

@@ -62,7 +62,7 @@ def _reparameterize_fused(rep, logits_map, config, noise, force=False):
     if training and (noise[0] is None or noise[1] is None):
         seed, offset = rng.next_call()
     z_q, z_p, _, _, clamped, kl_pair, kl_prior, means = F_.gauss_pair(
-        enc, pri, noise[0], noise[1], eps_tol=EPS_TOL, training=training, with_prior_kl=True, seed=seed,
+        enc, pri, noise[0], noise[1], eps_tol=rep.eps_tol, training=training, with_prior_kl=True, seed=seed,
         offset=offset, row0=rep.row_offset, mean_scale=rep.mean_scale, want_logvars=False)
     mu_q = torch.narrow(enc, -1, 0, L)
     mu_p = torch.narrow(clamped, -1, 0, L)
@@ -73,8 +73,9 @@ def _reparameterize_fused(rep, logits_map, config, noise, force=False):
     g_p = LazyParams({'z': z_p, 'mu': mu_p, 'mu_mean': means[2], 'logvar_mean': means[3]})
     # the logvar entries are the reference's own ops (isotropic_gaussian.py:124-125 on the encoder logits and on the
     # clamped prior logits), run only if somebody reads them: both KLs already came out of the launch
-    g_q.set_lazy('logvar', lambda: torch.narrow(enc, -1, L, L) + EPS_TOL)
-    g_p.set_lazy('logvar', lambda: torch.narrow(clamped, -1, L, L) + EPS_TOL)
+    eps = rep.eps_tol
+    g_q.set_lazy('logvar', lambda: torch.narrow(enc, -1, L, L) + eps)
+    g_p.set_lazy('logvar', lambda: torch.narrow(clamped, -1, L, L) + eps)
     g_q._vae_amd_kl_pair = (kl_pair, g_p)        # KL(post || prior), valid against exactly this prior
     g_p._vae_amd_kl = (kl_prior, mu_p)           # KL(prior || N(0,1))
     logits_map['prior_logits'] = clamped
