@@ -376,3 +376,136 @@ def test_conditioned_prior_golden(golden, name):
     close(gl, g['grad_logits'], rtol=1e-4, atol=1e-5)
     close(gw, g['grad_mlp_weight'], rtol=1e-4, atol=1e-5)
     close(gb, g['grad_mlp_bias'], rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------ config 4 end to end
+def ref_cfg(**kw):
+    """The reference's own config keys for a Gaussian -> Flow chain (tests/golden/make_golden.py: base_config)."""
+    c = {'continuous_size': 8, 'discrete_size': 5, 'half': False, 'cuda': True, 'epochs': 10,
+         'continuous_mut_info': 0, 'discrete_mut_info': 0, 'kl_beta': 1.0, 'use_prior_kl': False,
+         'flow_type': 'maf', 'latent_size': 16, 'memory_read_steps': 1, 'reparam_type': 'isotropic_gaussian'}
+    c.update(kw)
+    return c
+
+
+def test_flow_reparameterizer_builds_from_reference_config(golden):
+    """FlowReparameterizer(config) with flow_type / continuous_size / latent_size only (flow.py:20-49), the
+    reference's own state_dict loaded strictly, its eval-mode forward and "KL" reproduced."""
+    from vae_amd.reparameterizers import FlowReparameterizer
+    g = golden('flow')['flow_forward']
+    m = FlowReparameterizer(ref_cfg(continuous_size=6, latent_size=16))
+    m.load_state_dict(g['state_dict'], strict=True)
+    m = m.to(DEV).eval()
+    f, p = m(g['x'].to(DEV))
+    assert set(p) == {'recon_x', 'logdet'} and p['logdet'].shape == g['logdet'].shape
+    close(f, g['flow'], rtol=1e-5, atol=1e-5)
+    close(p['logdet'], g['logdet'], rtol=1e-5, atol=1e-5)
+    close(m.kl(p), g['kl'], rtol=1e-5, atol=1e-5)
+    assert m.input_size == 6 and m.output_size == 6
+    for ft in ('maf_split', 'realnvp'):
+        FlowReparameterizer(ref_cfg(continuous_size=6, flow_type=ft, dense_normalization='none'))
+    for ft in ('glow', 'maf_split_glow'):
+        with pytest.raises(NotImplementedError):
+            FlowReparameterizer(ref_cfg(flow_type=ft))
+
+
+def test_sequential_gauss_flow_golden_end_to_end(golden):
+    """SequentialReparameterizer(['isotropic_gaussian', 'flow'], cfg) from the reference's config alone, the
+    reference's state_dict (Gaussian -> Linear -> 5 x (MADE, BatchNormFlow, Reverse)) loaded strictly, its noise
+    injected: z, every params entry, kl and d/d logits of (z.sum() + kl.sum()) against the reference's own run."""
+    from vae_amd.reparameterizers import SequentialReparameterizer
+    g = golden('sequential')['sequential_gauss_flow']
+    m = SequentialReparameterizer(['isotropic_gaussian', 'flow'], ref_cfg(continuous_size=8, latent_size=16))
+    assert m.input_size == g['input_size'] and m.output_size == g['output_size']
+    m.load_state_dict(g['state_dict'], strict=True)
+    m = m.to(DEV).train(True)
+    logits = g['logits'].to(DEV).requires_grad_(True)
+    z, params = m(logits, noise=[g['noise'].to(DEV), None])
+    assert set(params) == {'logits', 'sequential'} and len(params['sequential']) == 2
+    want0, want1 = g['params']['sequential']
+    got0, got1 = params['sequential']
+    assert set(got0) == set(want0) and set(got1) == set(want1) and set(got0['gaussian']) == set(want0['gaussian'])
+    assert torch.equal(got0['z'].detach().cpu(), want0['z'])                       # the Gaussian draw: bit-exact
+    assert torch.equal(got0['gaussian']['logvar'].detach().cpu(), want0['gaussian']['logvar'])
+    close(got0['gaussian']['mu_mean'], want0['gaussian']['mu_mean'], rtol=1e-5, atol=1e-6)
+    close(got1['recon_x'], want1['recon_x'], rtol=1e-5, atol=1e-5)
+    close(got1['logdet'], want1['logdet'], rtol=1e-5, atol=1e-5)
+    close(z, g['z'], rtol=1e-5, atol=1e-5)
+    kl = m.kl(params)
+    close(kl, g['kl'], rtol=1e-5, atol=1e-4)
+    (gl,) = torch.autograd.grad(z.sum() + kl.sum(), logits)
+    close(gl, g['grad_logits'], rtol=1e-4, atol=1e-4)
+
+
+def _maf_oracle(sd, prefix, x, nblocks, training):
+    """CPU restatement of FlowSequential(5 x (MADE(tanh), BatchNormFlow, Reverse)) from a state_dict, through the
+    oracle's tails (flows/__init__.py:176-178, 233-257, 403-406, 555-557)."""
+    import torch.nn.functional as Fn
+    logdet = torch.zeros(x.shape[0], 1, dtype=x.dtype)
+    for b in range(nblocks):
+        p = '%s%d.' % (prefix, 3 * b)
+        lin = lambda h, name: Fn.linear(h, sd[p + name + '.linear.weight'] * sd[p + name + '.mask'],
+                                        sd[p + name + '.linear.bias'])
+        ma = lin(torch.tanh(lin(torch.tanh(lin(x, 'joiner')), 'trunk.1')), 'trunk.3')
+        u, ld = O.made_tail(x, *ma.chunk(2, 1))
+        q = '%s%d.' % (prefix, 3 * b + 1)
+        y, ld2, _, _ = O.bnflow(u, sd[q + 'log_gamma'], sd[q + 'beta'], sd[q + 'running_mean'], sd[q + 'running_var'],
+                                training)
+        x, logdet = O.reverse_columns(y), logdet + ld + ld2
+    return x, logdet
+
+
+def test_config4_chain_full_size():
+    """BASELINE configs[3] at size: B = 8192, Gaussian(L = 128) -> dense -> MAF(F = 256, 5 blocks), 3x64x64
+    discretized-logistic NLL, through the drop-in classes built from the reference's config keys alone.
+    Checked: the chain's sample, logdet and KL against the CPU oracle with the same weights and noise; the loss
+    dict's size-independent properties (elbo == nll + kld per sample, means == means of the vectors); and shard
+    invariance of every per-sample output in eval mode (batch statistics make training-mode shards differ by
+    construction: vae_amd.dist reduces them, tests/test_gpu_dist.py)."""
+    from vae_amd.reparameterizers import SequentialReparameterizer
+    from vae_amd import elbo as E
+    torch.manual_seed(4)
+    B, L = 8192, 128
+    c = ref_cfg(continuous_size=2 * L, latent_size=256, nll_type='disc_logistic')
+    m = SequentialReparameterizer(['isotropic_gaussian', 'flow'], c).to(DEV).train(True)
+    logits, noise = torch.randn(B, 2 * L), torch.randn(B, L)
+    lg = logits.to(DEV).requires_grad_(True)
+    z, params = m(lg, noise=[noise.to(DEV), None])
+    kl = m.kl(params)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    z0, p0 = O.gauss_forward(logits, noise)
+    h = torch.nn.functional.linear(z0, sd['reparameterizers.1.0.weight'], sd['reparameterizers.1.0.bias'])
+    u0, ld0 = _maf_oracle(sd, 'reparameterizers.1.1.flow.', h, 5, True)
+    k0 = O.gauss_kl(p0) + O.flow_kl({'recon_x': u0, 'logdet': ld0})
+    close(z, u0, rtol=1e-4, atol=1e-3)
+    close(params['sequential'][1]['logdet'], ld0, rtol=1e-4, atol=1e-2)
+    close(kl, k0, rtol=1e-4, atol=5e-2)
+    # the loss over 3x64x64 images
+    x = (torch.floor(torch.rand(B, 3, 64, 64, device=DEV) * 256) / 255.0).clamp(0, 1)
+    recon = torch.randn(B, 6, 64, 64, device=DEV, requires_grad=True)
+    out = E.loss_function(recon, x, kl, 'disc_logistic', kl_beta=1.0)
+    assert out['loss'].shape == (B,) and out['elbo'].shape == (B,)
+    nll = E.nll(x, recon, 'disc_logistic')
+    close(out['elbo'], nll + kl, rtol=1e-6, atol=1e-2)
+    close(out['elbo_mean'], out['elbo'].double().mean().float(), rtol=1e-5)
+    close(out['kld_mean'], kl.double().mean().float(), rtol=1e-5)
+    close(out['nll_mean'], nll.double().mean().float(), rtol=1e-5)
+    (out['loss_mean'] + z.mean()).backward()
+    assert bool(torch.isfinite(lg.grad).all()) and bool(torch.isfinite(recon.grad).all())
+    # eval mode: rows are independent -> two half-batch calls equal the full call, row for row
+    m.eval()
+    with torch.no_grad():
+        zf, pf = m(lg)
+        klf = m.kl(pf)
+        za, pa = m(lg[:B // 2])
+        zb, pb = m(lg[B // 2:])
+        # the stock GEMMs in between pick their kernels by M: to rounding, not bit for bit (the kernels' own outputs
+        # are: the Gaussian KL below, tests/test_gpu_fullsize.py)
+        close(torch.cat([za, zb]), zf, rtol=1e-5, atol=1e-5)
+        # the Flow "KL" is a cross-batch mean (SURVEY Q6): only the per-sample part kl + logdet - mean is shardable
+        ga = m.reparameterizers[0].kl(pa['sequential'][0])
+        gf = m.reparameterizers[0].kl(pf['sequential'][0])
+        assert torch.equal(ga, gf[:B // 2])
+        close(torch.cat([pa['sequential'][1]['logdet'], pb['sequential'][1]['logdet']]),
+              pf['sequential'][1]['logdet'], rtol=1e-5, atol=1e-4)
+        assert klf.shape == (B,)

@@ -1,7 +1,6 @@
-"""FlowReparameterizer with the reference's interface (reparameterizers/flow.py).  The flow network
-is a stock PyTorch module supplied by the host project (the reference builds it from its own
-flows/ package, out of scope per SURVEY section 2); only the "KL" reduction is on the hot path and
-runs in the HIP kernel, in O(B*F) instead of the reference's accidental [B,B] intermediate."""
+"""FlowReparameterizer with the reference's interface (reparameterizers/flow.py): constructed from the reference's
+config (flow_type / continuous_size / latent_size), its "KL" reduction in the HIP kernel in O(B*F) instead of the
+reference's accidental [B,B] intermediate, its MADE / coupling / BatchNormFlow tails in csrc/flowtail.hip."""
 import torch
 import torch.nn as nn
 
@@ -9,11 +8,16 @@ from .. import functional as F_
 
 
 class FlowReparameterizer(nn.Module):
-    """A fully flow based reparameterizer.
+    """A fully flow based reparameterizer, built from the reference's own config keys (flow.py:20-49):
+    config['flow_type'] in {'maf', 'maf_split', 'realnvp'} with config['continuous_size'] features,
+    config['latent_size'] hidden units and 5 blocks, through vae_amd.flows' builders (same layer classes, ctor
+    arguments and state_dict keys as flows/__init__.py, so the reference's checkpoints load; the elementwise tails
+    run in csrc/flowtail.hip).  The two glow variants need ActNorm / InvertibleMM / LUInvertibleMM layers, which stay
+    the host project's stock PyTorch: NotImplementedError names them.
 
-    config['flow_module'] (an nn.Module whose forward(x[N,F]) returns (u[N,F], logdet[N,1]) and that
-    has `.sample(num_samples, noise)`), or config['flow_builder'] (callable(config) -> such a module),
-    stands in for the reference's `flows.build_*_flow` call (flow.py:26-49)."""
+    Overrides (not in the reference): config['flow_module'] -- an nn.Module whose forward(x[N,F]) returns
+    (u[N,F], logdet[N,1]) and that has `.sample(num_samples, noise)` -- or config['flow_builder'],
+    callable(config) -> such a module, replace the built flow."""
 
     def __init__(self, config):
         super(FlowReparameterizer, self).__init__()
@@ -24,8 +28,28 @@ class FlowReparameterizer(nn.Module):
         elif config.get('flow_builder') is not None:
             self.flow = config['flow_builder'](config)
         else:
-            raise ValueError("FlowReparameterizer needs config['flow_module'] or config['flow_builder']: the flow "
-                             "networks are stock PyTorch modules of the host project (reference flows/)")
+            from .. import flows
+            flow_type, latent_size = config['flow_type'], config['latent_size']
+            if flow_type == 'maf':
+                self.flow = flows.build_maf_flow(num_inputs=continuous_size, num_hidden=latent_size,
+                                                 num_cond_inputs=None, num_blocks=5, activation_str='tanh')
+            elif flow_type == 'maf_split':
+                self.flow = flows.build_maf_split_flow(num_inputs=continuous_size, num_hidden=latent_size,
+                                                       num_cond_inputs=None, num_blocks=5, s_activation_str='tanh',
+                                                       t_activation_str='relu')
+            elif flow_type == 'realnvp':
+                self.flow = flows.build_realnvp_flow(num_inputs=continuous_size, num_hidden=latent_size,
+                                                     num_cond_inputs=None, num_blocks=5, s_activation_str='tanh',
+                                                     t_activation_str='relu',
+                                                     normalization_str=config.get('dense_normalization', 'none'),
+                                                     cuda=config.get('cuda', True))
+            elif flow_type in ('glow', 'maf_split_glow'):
+                raise NotImplementedError(
+                    "flow_type '%s' is built from ActNorm / InvertibleMM / LUInvertibleMM layers (flows/__init__.py:"
+                    "260-400), stock PyTorch modules of the host project: pass the built flow as "
+                    "config['flow_module'] (or config['flow_builder'])" % flow_type)
+            else:
+                raise ValueError("unknown flow_type '%s'" % (flow_type,))
         self.input_size = continuous_size
         self.output_size = continuous_size
         self.inv_count = None    # 1/B_global when sharded

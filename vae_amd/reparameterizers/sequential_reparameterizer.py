@@ -1,91 +1,89 @@
 """SequentialReparameterizer with the reference's interface
-(reparameterizers/sequential_reparameterizer.py): reparam0 -> dense -> reparam1 -> ...; KLs summed
-over params['sequential'].  The dense projections are stock PyTorch (the reference takes them from
-helpers.layers.get_encoder, un-vendored): config['dense_builder'](input_size, output_size, name) may
-supply the host project's builder, default one nn.Linear."""
+(reparameterizers/sequential_reparameterizer.py:10-164): a chain  leaf0 -> dense -> leaf1 -> dense -> leaf2 ...
+whose sample is the last leaf's output and whose KL is the sum of the leaves' KLs over params['sequential'].
+
+Layout contract kept for drop-in use and checkpoints: `self.reparameterizers` is an nn.ModuleList whose first entry
+is the first leaf and whose later entries are nn.Sequential(dense, leaf) (state_dict keys `reparameterizers.i.0.*`
+for the projection, `reparameterizers.i.1.*` for the leaf: tests/golden/sequential.pt is the reference's own
+state_dict and loads as is); attributes `reparam_strs`, `input_size`, `output_size`, `config`.
+
+The dense projections are stock PyTorch (the reference takes them from helpers.layers.get_encoder, un-vendored):
+config['dense_builder'](input_size, output_size, name) may supply the host project's builder, default one nn.Linear.
+Every leaf's sample and KL runs in its own fused kernels (Gaussian: csrc/gauss.hip, Flow: csrc/flowtail.hip +
+csrc/flow.hip); `forward(..., noise=[...])` injects one noise tensor (or None) per leaf.
+"""
 import torch.nn as nn
 
 
 class SequentialReparameterizer(nn.Module):
     def __init__(self, reparam_strs, config):
         super(SequentialReparameterizer, self).__init__()
+        from . import get_reparameterizer
         self.config = config
         self.reparam_strs = reparam_strs
-        self.reparameterizers = nn.ModuleList(self._generate_reparameterizers())
-        self.input_size = self.reparameterizers[0].input_size
-        self.output_size = self.reparameterizers[-1][-1].output_size \
-            if len(self.reparameterizers) > 1 else self.reparameterizers[-1].output_size
+        leaves = [get_reparameterizer(name)(config=config) for name in reparam_strs]
+        stages = [leaves[0]]
+        for i, leaf in enumerate(leaves[1:], start=1):
+            # leaf i reads what leaf i-1 emits, through a learned projection (reference :38-69)
+            proj = self._get_dense_net(leaves[i - 1].output_size, leaf.input_size, name='reparam_proj{}'.format(i))
+            stages.append(nn.Sequential(proj, leaf))
+        self.reparameterizers = nn.ModuleList(stages)
+        self.input_size = leaves[0].input_size
+        self.output_size = leaves[-1].output_size
 
     def _get_dense_net(self, input_size, output_size, name='dense'):
         builder = self.config.get('dense_builder')
-        if builder is not None:
-            return builder(input_size, output_size, name)
-        return nn.Linear(input_size, output_size)
+        return builder(input_size, output_size, name) if builder is not None else nn.Linear(input_size, output_size)
 
-    def _append_inter_projection(self, reparam, input_size, output_size, name):
-        return nn.Sequential(self._get_dense_net(input_size, output_size, name), reparam)
-
-    def _generate_reparameterizers(self):
-        from . import get_reparameterizer
-        reparam_list = [get_reparameterizer(reparam)(config=self.config) for reparam in self.reparam_strs]
-        input_size = reparam_list[0].output_size
-        for i in range(1, len(reparam_list)):
-            reparam_list[i] = self._append_inter_projection(reparam_list[i], input_size=input_size,
-                                                            output_size=reparam_list[i].input_size,
-                                                            name='reparam_proj{}'.format(i))
-            input_size = reparam_list[i][-1].output_size
-        return reparam_list
-
-    @staticmethod
-    def _leaf(reparam):
-        return reparam[-1] if isinstance(reparam, nn.Sequential) else reparam
+    def _chain(self):
+        """(projection modules in order, leaf) per stage; stage 0 has no projection."""
+        from . import is_module_a_reparameterizer
+        for stage in self.reparameterizers:
+            if isinstance(stage, nn.Sequential):
+                mods = list(stage)
+                split = [is_module_a_reparameterizer(m) for m in mods]
+                assert split[-1] and not any(split[:-1]), "a stage is projection layers followed by one reparameterizer"
+                yield mods[:-1], mods[-1]
+            else:
+                yield [], stage
 
     def get_reparameterizer_scalars(self):
-        reparam_scalar_map = {}
-        for i, reparam in enumerate(self.reparameterizers):
-            for k, v in self._leaf(reparam).get_reparameterizer_scalars().items():
-                reparam_scalar_map["{}{}".format(i, k)] = v
-        return reparam_scalar_map
+        return {"{}{}".format(i, k): v for i, (_, leaf) in enumerate(self._chain())
+                for k, v in leaf.get_reparameterizer_scalars().items()}
 
     def mutual_info(self, dists):
-        dist_params, mi = dists['concat'], None   # sic: the reference reads 'concat' here (:97)
-        for param, reparam in zip(dist_params, self.reparameterizers):
-            m = self._leaf(reparam).mutual_info(param)
-            mi = m if mi is None else mi + m
-        return mi
+        # the reference reads the parameter list under 'concat' here (:97), not 'sequential': kept
+        terms = [leaf.mutual_info(p) for p, (_, leaf) in zip(dists['concat'], self._chain())]
+        return sum(terms[1:], terms[0]) if terms else None
 
     def kl(self, dists, priors=None):
-        dist_params = dists['sequential']
-        priors = [None for _ in range(len(dist_params))] if priors is None else priors
-        assert len(priors) == len(dist_params)
-        kl = None
-        for param, prior, reparam in zip(dist_params, priors, self.reparameterizers):
-            k = self._leaf(reparam).kl(param, prior)
-            kl = k if kl is None else kl + k
-        return kl
+        """Sum over the leaves of leaf.kl(params_i, prior_i) (reference :104-122)."""
+        params = dists['sequential']
+        priors = [None] * len(params) if priors is None else priors
+        assert len(priors) == len(params)
+        terms = [leaf.kl(p, q) for p, q, (_, leaf) in zip(params, priors, self._chain())]
+        return sum(terms[1:], terms[0])
 
     def forward(self, logits, force=False, noise=None):
-        """`noise`: optional list with one injected noise tensor (or None) per child."""
-        from . import is_module_a_reparameterizer
+        """-> (last leaf's sample, {'logits': the input, 'sequential': [leaf params + that leaf's output under
+        'logits', ...]}) (reference :124-148).  `noise`: optional list, one tensor or None per leaf."""
         assert force is False, "force not implemented for sequential reparameterizer"
-        original_logits = logits
-        noise = [None] * len(self.reparameterizers) if noise is None else noise
-        kw = {} if noise[0] is None else {'noise': noise[0]}
-        logits, params = self.reparameterizers[0](logits, force=force, **kw)
-        params_list = [{**params, 'logits': logits}]
-        for i, reparam in enumerate(self.reparameterizers[1:], start=1):
-            for layer in reparam:
-                if is_module_a_reparameterizer(layer):
-                    kw = {} if noise[i] is None else {'noise': noise[i]}
-                    logits, params = layer(logits, force=force, **kw)
-                else:
-                    logits = layer(logits)
-            params_list.append({**params, 'logits': logits})
-        return logits, {'logits': original_logits, 'sequential': params_list}
+        stages = list(self._chain())
+        noise = [None] * len(stages) if noise is None else noise
+        h, collected = logits, []
+        for (projections, leaf), n in zip(stages, noise):
+            for p in projections:
+                h = p(h)
+            h, params = leaf(h, force=force) if n is None else leaf(h, force=force, noise=n)
+            collected.append({**params, 'logits': h})
+        return h, {'logits': logits, 'sequential': collected}
 
     def prior(self, batch_size, **kwargs):
-        prior = self.reparameterizers[0].prior(batch_size)
-        if len(self.reparameterizers) > 1:
-            for reparam in self.reparameterizers[1:]:
-                prior, _ = reparam(prior)
-        return prior
+        """A draw from the first leaf's prior pushed through the rest of the chain (reference :150-163)."""
+        stages = list(self._chain())
+        h = stages[0][1].prior(batch_size)
+        for projections, leaf in stages[1:]:
+            for p in projections:
+                h = p(h)
+            h, _ = leaf(h)
+        return h
