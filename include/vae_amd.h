@@ -47,6 +47,7 @@ enum { VAE_NLL_BERNOULLI = 0, VAE_NLL_GAUSSIAN = 1, VAE_NLL_DISC_LOGISTIC = 2 };
  * may be twice as long when K % 8 == 0); unaligned rows (K % 4 != 0) are limited to 1024.   */
 #define VAE_MAX_SOFTMAX_ROW 4096
 #define VAE_MAX_SAMPLES 8   /* decoder outputs one vae_nll_multi_elbo_* call combines */
+#define VAE_MAX_STEPS 128   /* time steps one vae_nll_steps_elbo_* call scores (pointer tables in the kernel arguments) */
 #define VAE_MAX_BN_ROW 4096 /* widest BatchNormFlow layer (F % 4 == 0 fp32 / F % 8 == 0 bf16; 1024 otherwise) */
 
 /* ABI version of this header; bumped on any signature change. */
@@ -288,6 +289,29 @@ int vae_nll_multi_elbo_fwd(const void* x, const void* const* recons, int64_t S, 
 int vae_nll_multi_elbo_bwd(const void* x, const void* const* recons, void* const* grecons, int64_t S, int nll_type,
                            const void* gnll, const void* gloss, const void* gelbo, const float* gmeans, float kl_beta,
                            float inv_count, void* gkld, void* gadd, void* gmi, int64_t B, int64_t D, int dtype,
+                           vae_stream_t stream);
+
+/* ---- VRNN / AdditiveVRNN loss over T time steps ------------------------------------------------
+ * vrnn.py:805-829 (loss_function: AbstractVAE.loss_function once per step, the per-step dicts summed by
+ * _add_loss_map :767-785 and divided by the step count by _mean_map :787-803), additive_vrnn.py:78-104.
+ * The T reconstructions and targets stay where the decoder and the data loader left them: xs / recons are HOST
+ * arrays of `steps` device pointers (1 <= steps <= VAE_MAX_STEPS), each a contiguous [B, D] / [B, D | 2D] tensor
+ * (a pointer may repeat: one target scored at every step), scored as one [steps * B] batch, step-major:
+ *   kld [steps*B] (the per-step KL vectors, one after the other) or NULL;
+ *   nll, loss, elbo [steps*B]: the per-step vectors;  loss_avg, elbo_avg [B]: their mean over the steps, summed
+ *   step by step in the tensor dtype as the reference does;  means: 6 floats = sums * inv_count
+ *   (inv_count = 1 / (steps * B_global): the mean over steps of the per-step means).
+ * No counterpart launch structure in the reference: ~40 launches per step there.                              */
+int vae_nll_steps_elbo_fwd(const void* const* xs, const void* const* recons, int64_t steps, int nll_type,
+                           const void* kld, float kl_beta, float inv_count, void* nll, void* loss, void* elbo,
+                           void* loss_avg, void* elbo_avg, float* means, float* workspace, int64_t B, int64_t D,
+                           int dtype, vae_stream_t stream);
+/* grecons: HOST array of `steps` device pointers, each written with d / d recons[t] (a reconstruction that is
+ * scored at several steps must be given distinct gradient buffers: the caller adds them up);  gnll, gloss,
+ * gelbo [steps*B] (each may be NULL), gmeans 6 floats or NULL;  gkld [steps*B] or NULL.                       */
+int vae_nll_steps_elbo_bwd(const void* const* xs, const void* const* recons, void* const* grecons, int64_t steps,
+                           int nll_type, const void* gnll, const void* gloss, const void* gelbo, const float* gmeans,
+                           float kl_beta, float inv_count, void* gkld, int64_t B, int64_t D, int dtype,
                            vae_stream_t stream);
 
 /* ---- flow-layer tails (flows/__init__.py; the masked linears / coupling nets stay stock GEMMs) -----

@@ -296,6 +296,112 @@ def test_vrnn_time_batched_loss_vs_per_step_oracle():
             assert out[k] == pytest.approx(v)
 
 
+def test_vrnn_loss_T64_full_step_vs_per_step_oracle():
+    """BASELINE configs[4] at its sequence length: T = 64 steps of B_step = 1024, 1x28x28 Bernoulli, the per-step
+    reconstructions and targets read in place (vae_nll_steps_elbo_fwd/bwd: pointer tables, no torch.cat) against the
+    reference's per-step loop + _add_loss_map / _mean_map (vrnn.py:767-829) on the CPU, forward and gradients."""
+    from vae_amd import vrnn as V
+    from vae_amd.reparameterizers import IsotropicGaussian
+    torch.manual_seed(8)
+    T, B, L = 64, 1024, 16
+    c = cfg(continuous_size=2 * L, use_prior_kl=False, kl_beta=0.7)
+    rep = IsotropicGaussian(c)
+    rep.train()
+    xs = [(torch.rand(B, 1, 28, 28) < 0.2).float() for _ in range(T)]
+    recons = [torch.randn(B, 1, 28, 28) for _ in range(T)]
+    encs = [torch.randn(B, 2 * L) for _ in range(T)]
+    pris = [torch.randn(B, 2 * L) for _ in range(T)]
+    n1 = [torch.randn(B, L) for _ in range(T)]
+    n2 = [torch.randn(B, L) for _ in range(T)]
+    w = torch.randn(B)
+    r0 = [r.clone().requires_grad_(True) for r in recons]
+    e0 = [e.clone().requires_grad_(True) for e in encs]
+    steps0 = []
+    for t in range(T):
+        _, p0 = O.vrnn_reparameterize(e0[t], pris[t], n1[t], n2[t])
+        steps0.append(O.loss_function(O.nll(xs[t], r0[t], 'bernoulli'), O.vrnn_kld(p0, False), 0.7))
+    ref = O.vrnn_loss(steps0)
+    g0 = torch.autograd.grad(ref['loss_mean'] + (ref['loss'] * w).sum() / B, [r0[0], r0[T - 1], e0[3]])
+    r1 = [r.to(DEV).requires_grad_(True) for r in recons]
+    e1 = [e.to(DEV).requires_grad_(True) for e in encs]
+    params1 = []
+    for t in range(T):
+        _, p1 = V.reparameterize(rep, {'encoder_logits': e1[t], 'prior_logits': pris[t].to(DEV), 'x_features': None}, c,
+                                 noise=(n1[t].to(DEV), n2[t].to(DEV)))
+        params1.append(p1)
+    out = V.loss_function(rep, c, r1, [x.to(DEV) for x in xs], params1)
+    assert set(out) == set(ref) and out['count'] == T and out['loss'].shape == (B,)
+    for k, v in ref.items():
+        if torch.is_tensor(v):
+            close(out[k], v, rtol=1e-5, atol=1e-3)
+    g1 = torch.autograd.grad(out['loss_mean'] + (out['loss'] * w.to(DEV)).sum() / B, [r1[0], r1[T - 1], e1[3]])
+    for a, b in zip(g1, g0):
+        close(a, b, rtol=1e-4, atol=2e-7 * max(1.0, float(b.abs().max()) * 1e4))
+
+
+def test_vrnn_loss_additive_scores_every_step_on_the_last_reconstruction():
+    """additive_vrnn.py:94-96: one target, the LAST reconstruction at every step -- the same tensor T times in the
+    pointer tables; its gradient is the sum over the steps."""
+    from vae_amd import vrnn as V
+    from vae_amd.reparameterizers import IsotropicGaussian
+    torch.manual_seed(9)
+    T, B, L = 4, 50, 6
+    c = cfg(continuous_size=2 * L, use_prior_kl=False, kl_beta=1.0)
+    rep = IsotropicGaussian(c)
+    rep.train()
+    x = (torch.rand(B, 1, 28, 28) < 0.2).float()
+    recons = [torch.randn(B, 1, 28, 28) for _ in range(T)]
+    encs, pris = [torch.randn(B, 2 * L) for _ in range(T)], [torch.randn(B, 2 * L) for _ in range(T)]
+    n1, n2 = [torch.randn(B, L) for _ in range(T)], [torch.randn(B, L) for _ in range(T)]
+    rl0 = recons[-1].clone().requires_grad_(True)
+    steps0 = []
+    for t in range(T):
+        _, p0 = O.vrnn_reparameterize(encs[t], pris[t], n1[t], n2[t])
+        steps0.append(O.loss_function(O.nll(x, rl0, 'bernoulli'), O.vrnn_kld(p0, False), 1.0))
+    ref = O.vrnn_loss(steps0)
+    (g0,) = torch.autograd.grad(ref['loss_mean'], rl0)
+    r1 = [r.to(DEV).requires_grad_(True) for r in recons]
+    params1 = []
+    for t in range(T):
+        _, p1 = V.reparameterize(rep, {'encoder_logits': encs[t].to(DEV), 'prior_logits': pris[t].to(DEV),
+                                       'x_features': None}, c, noise=(n1[t].to(DEV), n2[t].to(DEV)))
+        params1.append(p1)
+    out = V.loss_function(rep, c, r1, x.to(DEV), params1, additive=True)
+    for k, v in ref.items():
+        if torch.is_tensor(v):
+            close(out[k], v, rtol=1e-5, atol=1e-3)
+    g1 = torch.autograd.grad(out['loss_mean'], r1, allow_unused=True)
+    assert all(g is None or float(g.abs().max()) == 0.0 for g in g1[:-1])
+    close(g1[-1], g0, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize('nll_type', ['bernoulli', 'gaussian', 'disc_logistic'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_nll_steps_equals_concatenated_launch(nll_type, dtype):
+    """vae_nll_steps_elbo_fwd/bwd over T separate tensors == vae_nll_elbo_fwd/bwd over their concatenation, bit for
+    bit (same kernels, another row source), incl. a ragged B and a row length that takes the scalar path."""
+    from vae_amd import functional as F_
+    torch.manual_seed(12)
+    for T, B, D in ((3, 37, 75), (7, 5, 784), (2, 3, 12288)):
+        R = D if nll_type == 'bernoulli' else 2 * D
+        xs = [torch.rand(B, D).to(dtype).to(DEV) for _ in range(T)]
+        rs = [(torch.randn(B, R) * 1.5).to(dtype).to(DEV).requires_grad_(True) for _ in range(T)]
+        kld = torch.rand(T * B).to(dtype).to(DEV).requires_grad_(True)
+        w = torch.randn(T * B, device=DEV).to(dtype)
+        nll, loss, elbo, means, la, ea = F_.nll_steps_elbo(xs, rs, nll_type, kld=kld, kl_beta=0.6)
+        g = torch.autograd.grad((loss.float() * w.float()).sum() + means[0] + 2 * means[1], rs + [kld])
+        rc = torch.cat([r.detach() for r in rs], 0).requires_grad_(True)
+        kc = kld.detach().clone().requires_grad_(True)
+        n2, l2, e2, m2 = F_.nll_elbo(torch.cat(xs, 0), rc, nll_type, kld=kc, kl_beta=0.6)
+        g2 = torch.autograd.grad((l2.float() * w.float()).sum() + m2[0] + 2 * m2[1], [rc, kc])
+        assert torch.equal(nll, n2) and torch.equal(loss, l2) and torch.equal(elbo, e2) and torch.equal(means, m2)
+        assert torch.equal(torch.cat(g[:T], 0), g2[0]) and torch.equal(g[T], g2[1])
+        acc_l = loss.view(T, B)[0].clone()
+        for t in range(1, T):
+            acc_l = acc_l + loss.view(T, B)[t]
+        assert torch.equal(la, acc_l / T)
+
+
 @pytest.mark.parametrize('B,L', [(5, 3), (64, 128), (1000, 36), (257, 512)])
 @pytest.mark.parametrize('train', [True, False])
 def test_vrnn_fused_pair_backward_vs_oracle(B, L, train):

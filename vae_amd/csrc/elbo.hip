@@ -37,11 +37,10 @@ constexpr bool kNtNllFwd = VAE_NT_NLL_FWD != 0, kNtNllBwd = VAE_NT_NLL_BWD != 0;
 // ---------------------------------------------------------------------------
 // forward: nll[B] (+ loss[B], elbo[B], block partials of the six sums)
 // ---------------------------------------------------------------------------
-template <typename T, int V, int NLL, int U>
+template <typename T, int V, int NLL, int U, typename Src>
 __global__ __launch_bounds__(kBlock) void nll_elbo_fwd_kernel(
-    const T* __restrict__ x, const T* __restrict__ recon, const T* __restrict__ kld, const T* __restrict__ add,
-    const T* __restrict__ mi, T* __restrict__ nll_out, T* __restrict__ loss, T* __restrict__ elbo, int64_t B, int D,
-    float kl_beta, int G, int64_t tiles) {
+    Src src, const T* __restrict__ kld, const T* __restrict__ add, const T* __restrict__ mi, T* __restrict__ nll_out,
+    T* __restrict__ loss, T* __restrict__ elbo, int D, float kl_beta, int G, int64_t tiles) {
   const int rpb = kBlock / G;
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
@@ -49,17 +48,18 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_fwd_kernel(
   const int64_t rstride = (NLL == VAE_NLL_BERNOULLI) ? (int64_t)D : 2 * (int64_t)D;
 
   for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-    const int64_t row = t * rpb + rloc;
+    int64_t row;
+    const T *xr, *rr;
+    T* gr_unused;
+    const bool live = src.locate(t, rpb, rloc, D, rstride, row, xr, rr, gr_unused);
     float s = 0.f;
     float k = 0.f, ad = 0.f, m = 0.f;   // requested with the row (see nll_elbo_fused_kernel)
-    if (row < B) {
+    if (live) {
       if (loss) {
         if (kld) k = to_f32(kld[row]);
         if (add) ad = to_f32(add[row]);
         if (mi) m = to_f32(mi[row]);
       }
-      const T* xr = x + row * D;
-      const T* rr = recon + row * rstride;
       for (int j0 = sub; j0 < nvec; j0 += G * U) {
         float xv[U][V], a[U][V], b[U][V];
         load_chunk<T, V, U, kNtNllFwd>(xr, j0, G, nvec, xv);
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_fwd_kernel(
       }
     }
     s = row_sum(s, G);
-    if (row < B && sub == 0) {
+    if (live && sub == 0) {
       // round through the tensor dtype where the reference materialises a tensor
       const float n = to_f32(from_f32<T>(s));
       nll_out[row] = from_f32<T>(n);
@@ -97,14 +97,13 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_fwd_kernel(
 // backward: d recon (and the [B]-sized d kld / d add / d mi)
 //   c_nll[b] = gnll[b] + gloss[b] + gelbo[b] + (gm_loss + gm_elbo + gm_nll) * inv_count
 // ---------------------------------------------------------------------------
-template <typename T, int V, int NLL, int U>
+template <typename T, int V, int NLL, int U, typename Src>
 __global__ __launch_bounds__(kBlock) void nll_elbo_bwd_kernel(
-    const T* __restrict__ x, const T* __restrict__ recon, const T* __restrict__ gnll, const T* __restrict__ gloss,
-    const T* __restrict__ gelbo, const float* __restrict__ gmeans, T* __restrict__ grecon, T* __restrict__ gkld,
-    T* __restrict__ gadd, T* __restrict__ gmi, int64_t B, int D, float kl_beta, float inv_count, int G,
-    int64_t tiles) {
+    Src src, const T* __restrict__ gnll, const T* __restrict__ gloss, const T* __restrict__ gelbo,
+    const float* __restrict__ gmeans, T* __restrict__ gkld, T* __restrict__ gadd, T* __restrict__ gmi,
+    int64_t rows_total, int D, float kl_beta, float inv_count, int G, int64_t tiles) {
   const int rpb = kBlock / G;
-  const bool nts = nt_stores((int64_t)B * D * (int64_t)sizeof(T));
+  const bool nts = nt_stores(rows_total * D * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
   const int rloc = threadIdx.x / G;
   const int nvec = D / V;
@@ -114,8 +113,10 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_bwd_kernel(
   for (int k = 0; k < 6; ++k) gm[k] = gmeans ? gmeans[k] * inv_count : 0.f;
 
   for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-    const int64_t row = t * rpb + rloc;
-    if (row >= B) continue;
+    int64_t row;
+    const T *xr, *rr;
+    T* gr;
+    if (!src.locate(t, rpb, rloc, D, rstride, row, xr, rr, gr)) continue;
     const float gl = (gloss ? to_f32(gloss[row]) : 0.f) + gm[0];
     const float ge = (gelbo ? to_f32(gelbo[row]) : 0.f) + gm[1];
     const float c = (gnll ? to_f32(gnll[row]) : 0.f) + gl + ge + gm[2];
@@ -124,9 +125,6 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_bwd_kernel(
       if (gadd) gadd[row] = from_f32<T>(gl + gm[4]);
       if (gmi) gmi[row] = from_f32<T>(gm[5] - gl);
     }
-    const T* xr = x + row * D;
-    const T* rr = recon + row * rstride;
-    T* gr = grecon + row * rstride;
     for (int j0 = sub; j0 < nvec; j0 += G * U) {
       float xv[U][V], a[U][V], b[U][V];
       load_chunk<T, V, U, kNtNllBwd>(xr, j0, G, nvec, xv);
@@ -375,6 +373,41 @@ static int nll_fused_type(int nll_type, const void* x, const void* recon, const 
   return VAE_ERR_ARG;
 }
 
+// launch of the two general kernels over any row source (FlatRows / StepRows)
+template <typename T, int NLL, typename Src>
+static void nll_fwd_launch(const Src& src, bool vec, const RowGeom& g, int64_t tiles, const void* kld, const void* add,
+                           const void* mi, void* nll, void* loss, void* elbo, int64_t D, float kl_beta,
+                           hipStream_t stream) {
+  constexpr int VN = VecOf<T>::n;
+  const int grid = (int)(tiles < kGridStream ? tiles : kGridStream);
+  if (vec) {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_fwd_kernel<T, VN, NLL, U, Src>), dim3(grid), dim3(kBlock), 0, stream,
+                                         src, (const T*)kld, (const T*)add, (const T*)mi, (T*)nll, (T*)loss, (T*)elbo,
+                                         (int)D, kl_beta, g.G, tiles));
+  } else {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_fwd_kernel<T, 1, NLL, U, Src>), dim3(grid), dim3(kBlock), 0, stream,
+                                         src, (const T*)kld, (const T*)add, (const T*)mi, (T*)nll, (T*)loss, (T*)elbo,
+                                         (int)D, kl_beta, g.G, tiles));
+  }
+}
+
+template <typename T, int NLL, typename Src>
+static void nll_bwd_launch(const Src& src, bool vec, const RowGeom& g, int64_t tiles, int64_t rows_total,
+                           const void* gnll, const void* gloss, const void* gelbo, const float* gmeans, void* gkld,
+                           void* gadd, void* gmi, int64_t D, float kl_beta, float inv_count, hipStream_t stream) {
+  constexpr int VN = VecOf<T>::n;
+  const int grid = (int)(tiles < kGridStream ? tiles : kGridStream);
+  if (vec) {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_bwd_kernel<T, VN, NLL, U, Src>), dim3(grid), dim3(kBlock), 0, stream,
+                                         src, (const T*)gnll, (const T*)gloss, (const T*)gelbo, gmeans, (T*)gkld,
+                                         (T*)gadd, (T*)gmi, rows_total, (int)D, kl_beta, inv_count, g.G, tiles));
+  } else {
+    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_bwd_kernel<T, 1, NLL, U, Src>), dim3(grid), dim3(kBlock), 0, stream,
+                                         src, (const T*)gnll, (const T*)gloss, (const T*)gelbo, gmeans, (T*)gkld,
+                                         (T*)gadd, (T*)gmi, rows_total, (int)D, kl_beta, inv_count, g.G, tiles));
+  }
+}
+
 template <typename T, int NLL>
 static int nll_fwd_dispatch(const void* x, const void* recon, const void* kld, const void* add, const void* mi,
                             void* nll, void* loss, void* elbo, float* means, float* workspace, int64_t B, int64_t D,
@@ -382,15 +415,8 @@ static int nll_fwd_dispatch(const void* x, const void* recon, const void* kld, c
   constexpr int VN = VecOf<T>::n;
   const bool vec = (D % VN == 0) && aligned16(x) && aligned16(recon);
   const RowGeom g = nll_geom(B, vec ? D / VN : D, kGridStream);
-  if (vec) {
-    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_fwd_kernel<T, VN, NLL, U>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                         (const T*)x, (const T*)recon, (const T*)kld, (const T*)add, (const T*)mi,
-                                         (T*)nll, (T*)loss, (T*)elbo, B, (int)D, kl_beta, g.G, g.tiles));
-  } else {
-    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_fwd_kernel<T, 1, NLL, U>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                         (const T*)x, (const T*)recon, (const T*)kld, (const T*)add, (const T*)mi,
-                                         (T*)nll, (T*)loss, (T*)elbo, B, (int)D, kl_beta, g.G, g.tiles));
-  }
+  const FlatRows<T> src{(const T*)x, (const T*)recon, nullptr, B};
+  nll_fwd_launch<T, NLL>(src, vec, g, g.tiles, kld, add, mi, nll, loss, elbo, D, kl_beta, stream);
   if (loss && means) launch_rows_means<T>(loss, elbo, nll, kld, add, mi, workspace, inv_count, means, B, stream);
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
@@ -401,18 +427,61 @@ static int nll_bwd_dispatch(const void* x, const void* recon, const void* gnll, 
                             int64_t D, float kl_beta, float inv_count, hipStream_t stream) {
   constexpr int VN = VecOf<T>::n;
   const bool vec = (D % VN == 0) && aligned16(x) && aligned16(recon) && aligned16(grecon);
-  RowGeom g = nll_geom(B, vec ? D / VN : D, kGridStream, true);
-  if (vec) {
-    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_bwd_kernel<T, VN, NLL, U>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                         (const T*)x, (const T*)recon, (const T*)gnll, (const T*)gloss,
-                                         (const T*)gelbo, gmeans, (T*)grecon, (T*)gkld, (T*)gadd, (T*)gmi, B, (int)D,
-                                         kl_beta, inv_count, g.G, g.tiles));
-  } else {
-    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_bwd_kernel<T, 1, NLL, U>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                         (const T*)x, (const T*)recon, (const T*)gnll, (const T*)gloss,
-                                         (const T*)gelbo, gmeans, (T*)grecon, (T*)gkld, (T*)gadd, (T*)gmi, B, (int)D,
-                                         kl_beta, inv_count, g.G, g.tiles));
+  const RowGeom g = nll_geom(B, vec ? D / VN : D, kGridStream, true);
+  const FlatRows<T> src{(const T*)x, (const T*)recon, (T*)grecon, B};
+  nll_bwd_launch<T, NLL>(src, vec, g, g.tiles, B, gnll, gloss, gelbo, gmeans, gkld, gadd, gmi, D, kl_beta, inv_count,
+                         stream);
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+// ---- the same over T per-step tensors given by pointer (VRNN / AdditiveVRNN loss_function) ---------------------
+template <typename Tab>
+static bool fill_steps(Tab* tab, const void* const* xs, const void* const* recons, void* const* grecons, int64_t steps,
+                       bool* aligned) {
+  for (int64_t i = 0; i < steps; ++i) {
+    if (!xs[i] || !recons[i] || (grecons && !grecons[i])) return false;
+    tab->x[i] = xs[i];
+    tab->recon[i] = recons[i];
+    if (!aligned16(xs[i]) || !aligned16(recons[i]) || (grecons && !aligned16(grecons[i]))) *aligned = false;
+    if constexpr (sizeof(Tab) == sizeof(StepTableG)) tab->grecon[i] = grecons[i];
   }
+  return true;
+}
+
+template <typename T, int NLL>
+static int nll_steps_fwd_dispatch(const void* const* xs, const void* const* recons, int64_t steps, const void* kld,
+                                  void* nll, void* loss, void* elbo, void* loss_avg, void* elbo_avg, float* means,
+                                  float* workspace, int64_t B, int64_t D, float kl_beta, float inv_count,
+                                  hipStream_t stream) {
+  constexpr int VN = VecOf<T>::n;
+  StepRows<T, StepTable> src;
+  bool al = true;
+  if (!fill_steps(&src.tab, xs, recons, nullptr, steps, &al)) return VAE_ERR_ARG;
+  const bool vec = (D % VN == 0) && al;
+  const RowGeom g = nll_geom(B * steps, vec ? D / VN : D, kGridStream);   // geometry by the whole launch
+  src.B = B;
+  src.tps = (B + g.rows_per_block - 1) / g.rows_per_block;                // tiles never straddle steps
+  nll_fwd_launch<T, NLL>(src, vec, g, src.tps * steps, kld, nullptr, nullptr, nll, loss, elbo, D, kl_beta, stream);
+  launch_rows_means<T>(loss, elbo, nll, kld, nullptr, nullptr, workspace, inv_count, means, B * steps, stream, steps,
+                       loss_avg, elbo_avg);
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
+template <typename T, int NLL>
+static int nll_steps_bwd_dispatch(const void* const* xs, const void* const* recons, void* const* grecons, int64_t steps,
+                                  const void* gnll, const void* gloss, const void* gelbo, const float* gmeans,
+                                  void* gkld, int64_t B, int64_t D, float kl_beta, float inv_count,
+                                  hipStream_t stream) {
+  constexpr int VN = VecOf<T>::n;
+  StepRows<T, StepTableG> src;
+  bool al = true;
+  if (!fill_steps(&src.tab, xs, recons, grecons, steps, &al)) return VAE_ERR_ARG;
+  const bool vec = (D % VN == 0) && al;
+  const RowGeom g = nll_geom(B * steps, vec ? D / VN : D, kGridStream, true);
+  src.B = B;
+  src.tps = (B + g.rows_per_block - 1) / g.rows_per_block;
+  nll_bwd_launch<T, NLL>(src, vec, g, src.tps * steps, B * steps, gnll, gloss, gelbo, gmeans, gkld, nullptr, nullptr, D,
+                         kl_beta, inv_count, stream);
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 
@@ -523,6 +592,58 @@ int vae_nll_elbo_bwd(const void* x, const void* recon, int nll_type, const void*
   if (dtype == VAE_F16)
     return nll_bwd_type<f16_t>(nll_type, x, recon, gnll, gloss, gelbo, gmeans, grecon, gkld, gadd, gmi, B, D,
                                 kl_beta, inv_count, st);
+  return VAE_ERR_ARG;
+}
+
+int vae_nll_steps_elbo_fwd(const void* const* xs, const void* const* recons, int64_t steps, int nll_type,
+                           const void* kld, float kl_beta, float inv_count, void* nll, void* loss, void* elbo,
+                           void* loss_avg, void* elbo_avg, float* means, float* workspace, int64_t B, int64_t D,
+                           int dtype, vae_stream_t stream) {
+  if (B < 0 || D <= 0 || D > VAE_MAX_ROW || steps < 1 || steps > VAE_MAX_STEPS) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  if (!xs || !recons || !nll || !loss || !elbo || !loss_avg || !elbo_avg || !means || !workspace) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+#define VAE_STEPS_FWD(TT, NN)                                                                                        \
+  return nll_steps_fwd_dispatch<TT, NN>(xs, recons, steps, kld, nll, loss, elbo, loss_avg, elbo_avg, means, workspace, \
+                                        B, D, kl_beta, inv_count, st)
+#define VAE_STEPS_FWD_T(TT)                                       \
+  switch (nll_type) {                                             \
+    case VAE_NLL_BERNOULLI: VAE_STEPS_FWD(TT, VAE_NLL_BERNOULLI); \
+    case VAE_NLL_GAUSSIAN: VAE_STEPS_FWD(TT, VAE_NLL_GAUSSIAN);   \
+    case VAE_NLL_DISC_LOGISTIC: VAE_STEPS_FWD(TT, VAE_NLL_DISC_LOGISTIC); \
+  }                                                               \
+  return VAE_ERR_ARG
+  if (dtype == VAE_F32) { VAE_STEPS_FWD_T(float); }
+  if (dtype == VAE_BF16) { VAE_STEPS_FWD_T(bf16_t); }
+  if (dtype == VAE_F16) { VAE_STEPS_FWD_T(f16_t); }
+#undef VAE_STEPS_FWD_T
+#undef VAE_STEPS_FWD
+  return VAE_ERR_ARG;
+}
+
+int vae_nll_steps_elbo_bwd(const void* const* xs, const void* const* recons, void* const* grecons, int64_t steps,
+                           int nll_type, const void* gnll, const void* gloss, const void* gelbo, const float* gmeans,
+                           float kl_beta, float inv_count, void* gkld, int64_t B, int64_t D, int dtype,
+                           vae_stream_t stream) {
+  if (B < 0 || D <= 0 || D > VAE_MAX_ROW || steps < 1 || steps > VAE_MAX_STEPS) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  if (!xs || !recons || !grecons) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+#define VAE_STEPS_BWD(TT, NN)                                                                                       \
+  return nll_steps_bwd_dispatch<TT, NN>(xs, recons, grecons, steps, gnll, gloss, gelbo, gmeans, gkld, B, D, kl_beta, \
+                                        inv_count, st)
+#define VAE_STEPS_BWD_T(TT)                                       \
+  switch (nll_type) {                                             \
+    case VAE_NLL_BERNOULLI: VAE_STEPS_BWD(TT, VAE_NLL_BERNOULLI); \
+    case VAE_NLL_GAUSSIAN: VAE_STEPS_BWD(TT, VAE_NLL_GAUSSIAN);   \
+    case VAE_NLL_DISC_LOGISTIC: VAE_STEPS_BWD(TT, VAE_NLL_DISC_LOGISTIC); \
+  }                                                               \
+  return VAE_ERR_ARG
+  if (dtype == VAE_F32) { VAE_STEPS_BWD_T(float); }
+  if (dtype == VAE_BF16) { VAE_STEPS_BWD_T(bf16_t); }
+  if (dtype == VAE_F16) { VAE_STEPS_BWD_T(f16_t); }
+#undef VAE_STEPS_BWD_T
+#undef VAE_STEPS_BWD
   return VAE_ERR_ARG;
 }
 

@@ -3,6 +3,7 @@
 // ("parity unpinned", see oracle/cpu_ref.py).
 #pragma once
 #include "common.hpp"
+#include "../../include/vae_amd.h"
 
 namespace vae {
 
@@ -75,6 +76,54 @@ __device__ __forceinline__ void nll_dlog_grad(float x, float a, float v, float& 
   gv = (dp * (-tp) + dm * (-t)) * inside;
 }
 
+// Where the rows of an NLL launch live.  FlatRows: one [B, D] target and one [B, D | 2D] decoder output (and its
+// gradient).  StepRows: T such pairs given by pointer -- the per-step reconstructions and targets of a VRNN
+// (vrnn.py:805-829) as the decoder left them, no torch.cat copy -- indexed as one [T*B] batch, step-major; a tile
+// never straddles two steps, so the step (and with it the table lookup) is uniform over a block.
+template <typename T>
+struct FlatRows {
+  const T* x;
+  const T* recon;
+  T* grecon;
+  int64_t B;
+  __device__ __forceinline__ bool locate(int64_t tile, int rpb, int rloc, int64_t D, int64_t rstride, int64_t& row,
+                                         const T*& xr, const T*& rr, T*& gr) const {
+    row = tile * rpb + rloc;
+    if (row >= B) return false;
+    xr = x + row * D;
+    rr = recon + row * rstride;
+    gr = grecon + row * rstride;
+    return true;
+  }
+};
+struct StepTable {
+  const void* x[VAE_MAX_STEPS];
+  const void* recon[VAE_MAX_STEPS];
+};
+struct StepTableG {
+  const void* x[VAE_MAX_STEPS];
+  const void* recon[VAE_MAX_STEPS];
+  void* grecon[VAE_MAX_STEPS];
+};
+template <typename T, typename Tab>
+struct StepRows {
+  Tab tab;
+  int64_t B;     // rows per step
+  int64_t tps;   // tiles per step = ceil(B / rows_per_block)
+  __device__ __forceinline__ bool locate(int64_t tile, int rpb, int rloc, int64_t D, int64_t rstride, int64_t& row,
+                                         const T*& xr, const T*& rr, T*& gr) const {
+    const int64_t step = tile / tps;
+    const int64_t b = (tile - step * tps) * rpb + rloc;
+    row = step * B + b;
+    if (b >= B) return false;
+    xr = static_cast<const T*>(tab.x[step]) + b * D;
+    rr = static_cast<const T*>(tab.recon[step]) + b * rstride;
+    if constexpr (sizeof(Tab) == sizeof(StepTableG)) gr = static_cast<T*>(tab.grecon[step]) + b * rstride;
+    else gr = nullptr;
+    return true;
+  }
+};
+
 // Long rows with few samples: give a row to the whole block so the chip stays full.
 // `long_rows_always`: the store-heavy backward of 3x64x64 rows measured 3-4 points faster block-per-row at any B
 // (fewer concurrent DRAM streams: 5 per block instead of 5 per wave); the forward is not (r01, B=8192).
@@ -105,7 +154,25 @@ __global__ __launch_bounds__(kBlock) void elbo_rows_means_kernel(const T* __rest
                                                                  const T* __restrict__ nll, const T* __restrict__ kld,
                                                                  const T* __restrict__ add, const T* __restrict__ mi,
                                                                  float* __restrict__ ws, float inv_count,
-                                                                 float* __restrict__ means, int64_t B) {
+                                                                 float* __restrict__ means, int64_t B, int64_t steps,
+                                                                 T* __restrict__ loss_avg, T* __restrict__ elbo_avg) {
+  // per-sample averages over the steps of a [steps * Bs] launch (vrnn.py:767-803: the per-step [B] vectors are
+  // summed one after the other in the tensor dtype, then divided by the step count)
+  if (loss_avg) {
+    const int64_t Bs = B / steps;
+    const float inv_steps = div_rn(1.0f, (float)steps);
+    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < Bs; b += (int64_t)gridDim.x * kBlock) {
+      float sl = to_f32(loss[b]), se = to_f32(elbo[b]);
+      for (int64_t t = 1; t < steps; ++t) {
+        sl = to_f32(from_f32<T>(add_rn(sl, to_f32(loss[t * Bs + b]))));
+        se = to_f32(from_f32<T>(add_rn(se, to_f32(elbo[t * Bs + b]))));
+      }
+      // tensor /= python_int on the device is a multiplication by the fp32 reciprocal in stock PyTorch (div_true
+      // with a CPU scalar divisor): the same here
+      loss_avg[b] = from_f32<T>(mul_rn(sl, inv_steps));
+      elbo_avg[b] = from_f32<T>(mul_rn(se, inv_steps));
+    }
+  }
   double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   const int64_t nvec = B / V;   // whole vectors; the B % V rows of the tail go to the first threads of block 0
   for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < nvec; j += (int64_t)gridDim.x * kBlock) {
@@ -140,8 +207,8 @@ __global__ __launch_bounds__(kBlock) void elbo_rows_means_kernel(const T* __rest
 
 template <typename T>
 inline void launch_rows_means(const void* loss, const void* elbo, const void* nll, const void* kld, const void* add,
-                              const void* mi, float* ws, float inv_count, float* means, int64_t B,
-                              hipStream_t stream) {
+                              const void* mi, float* ws, float inv_count, float* means, int64_t B, hipStream_t stream,
+                              int64_t steps = 1, void* loss_avg = nullptr, void* elbo_avg = nullptr) {
   constexpr int VN = VecOf<T>::n;
   const bool vec = aligned16(loss) && aligned16(elbo) && aligned16(nll) && (!kld || aligned16(kld)) &&
                    (!add || aligned16(add)) && (!mi || aligned16(mi));
@@ -150,10 +217,12 @@ inline void launch_rows_means(const void* loss, const void* elbo, const void* nl
   const int grid = (int)(blocks < 64 ? blocks : 64);
   if (vec)
     hipLaunchKernelGGL((elbo_rows_means_kernel<T, VN>), dim3(grid), dim3(kBlock), 0, stream, (const T*)loss, (const T*)elbo,
-                       (const T*)nll, (const T*)kld, (const T*)add, (const T*)mi, ws, inv_count, means, B);
+                       (const T*)nll, (const T*)kld, (const T*)add, (const T*)mi, ws, inv_count, means, B, steps,
+                       (T*)loss_avg, (T*)elbo_avg);
   else
     hipLaunchKernelGGL((elbo_rows_means_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, stream, (const T*)loss, (const T*)elbo,
-                     (const T*)nll, (const T*)kld, (const T*)add, (const T*)mi, ws, inv_count, means, B);
+                       (const T*)nll, (const T*)kld, (const T*)add, (const T*)mi, ws, inv_count, means, B, steps,
+                       (T*)loss_avg, (T*)elbo_avg);
 }
 
 }  // namespace vae

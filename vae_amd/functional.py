@@ -1021,6 +1021,73 @@ def nll_multi_elbo(x, recons, nll_type, kld=None, add=None, mi=None, kl_beta=1.0
     return total, loss, elbo, means
 
 
+MAX_STEPS = 128  # VAE_MAX_STEPS in include/vae_amd.h
+
+
+class _NllStepsElbo(torch.autograd.Function):
+    """T per-step (target, reconstruction) pairs scored as one [T*B] launch, the tensors read where they are."""
+
+    @staticmethod
+    def forward(ctx, kld, nll_code, kl_beta, inv_count, T, *tensors):
+        ctx.set_materialize_grads(False)
+        xs, recons = tensors[:T], tensors[T:]
+        dev = check_device(kld, *tensors)
+        B, D = xs[0].shape
+        dt = recons[0].dtype
+        new = lambda n: torch.empty((n,), dtype=dt, device=dev)
+        nll, loss, elbo, loss_avg, elbo_avg = new(T * B), new(T * B), new(T * B), new(B), new(B)
+        means = _scalars(6, dev, B)
+        with _Guard(dev):
+            call('vae_nll_steps_elbo_fwd', _lib.ptr_array(xs), _lib.ptr_array(recons), T, nll_code, ptr(kld), kl_beta,
+                 inv_count, ptr(nll), ptr(loss), ptr(elbo), ptr(loss_avg), ptr(elbo_avg), ptr(means),
+                 ptr(workspace(dev)), B, D, dtype_code(recons[0]), stream_ptr(dev))
+        ctx.save_for_backward(*tensors)
+        ctx.cfg = (nll_code, kl_beta, inv_count, T, kld is not None)
+        return nll, loss, elbo, means, loss_avg, elbo_avg
+
+    @staticmethod
+    def backward(ctx, gnll, gloss, gelbo, gmeans, gloss_avg, gelbo_avg):
+        nll_code, kl_beta, inv_count, T, has_kld = ctx.cfg
+        xs, recons = ctx.saved_tensors[:T], ctx.saved_tensors[T:]
+        dev = xs[0].device
+        B, D = xs[0].shape
+        gnll, gloss, gelbo = _dense(gnll), _dense(gloss), _dense(gelbo)
+        # a gradient on a per-sample average is 1/T of it on each step's entry ([T*B] vectors: tiny next to the pixels)
+        if gloss_avg is not None:
+            spread = (gloss_avg / T).repeat(T)
+            gloss = spread if gloss is None else gloss + spread
+        if gelbo_avg is not None:
+            spread = (gelbo_avg / T).repeat(T)
+            gelbo = spread if gelbo is None else gelbo + spread
+        gmeans = None if gmeans is None else gmeans.contiguous().float()
+        grecons = [torch.empty_like(r) for r in recons]
+        gkld = torch.empty((T * B,), dtype=recons[0].dtype, device=dev) if has_kld and ctx.needs_input_grad[0] else None
+        with _Guard(dev):
+            call('vae_nll_steps_elbo_bwd', _lib.ptr_array(xs), _lib.ptr_array(recons), _lib.ptr_array(grecons), T,
+                 nll_code, ptr(gnll), ptr(gloss), ptr(gelbo), ptr(gmeans), kl_beta, inv_count, ptr(gkld), B, D,
+                 dtype_code(recons[0]), stream_ptr(dev))
+        return (gkld, None, None, None, None) + (None,) * T + tuple(grecons)
+
+
+def nll_steps_elbo(xs, recons, nll_type, kld=None, kl_beta=1.0, inv_count=None):
+    """The VRNN loss (vrnn.py:805-829) over T = len(recons) time steps in one launch pair: xs / recons are the per-step
+    targets and decoder outputs (a tensor may repeat), kld the per-step KL vectors concatenated [T*B].
+    Returns (nll, loss, elbo [T*B], means float32[6], loss_avg, elbo_avg [B]); the means are over all T*B entries
+    (= the mean over steps of the per-step means), the averages are per sample over the steps."""
+    T = len(recons)
+    assert 1 <= T <= MAX_STEPS and len(xs) == T
+    flat = [_flat_pixels(x, r, nll_type) for x, r in zip(xs, recons)]
+    code = flat[0][0]
+    xf, rf = [f[1] for f in flat], [f[2] for f in flat]
+    B = xf[0].shape[0]
+    for a, b in zip(xf, rf):
+        if a.shape != xf[0].shape or b.shape != rf[0].shape or b.dtype != rf[0].dtype:
+            raise ValueError("nll_steps_elbo: every step must have the same shapes and dtype")
+    if inv_count is None:
+        inv_count = 1.0 / max(T * B, 1)
+    return _NllStepsElbo.apply(_dense(kld), code, float(kl_beta), float(inv_count), T, *xf, *rf)
+
+
 # --------------------------------------------------------------------------------------
 # Flow-layer tails (flows/__init__.py): MADE / MADESplit, coupling, BatchNormFlow (+ Reverse).
 # The running logdet of FlowSequential rides along as a [B] tensor (logdet_in -> logdet_out).

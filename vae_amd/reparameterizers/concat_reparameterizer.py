@@ -10,7 +10,7 @@ from .. import rng
 from ..lazy import LazyParams, hard_from_soft_max, hard_from_soft_threshold
 from .bernoulli import Bernoulli
 from .gumbel import GumbelSoftmax
-from .isotropic_gaussian import EPS_TOL, IsotropicGaussian
+from .isotropic_gaussian import IsotropicGaussian
 
 _FUSABLE = (IsotropicGaussian, GumbelSoftmax, Bernoulli)
 

@@ -12,9 +12,9 @@ import torch
 
 from . import functional as F_
 from . import rng
-from .elbo import _pack
+from .elbo import _pack, vrnn_loss_function
 from .lazy import LazyParams
-from .reparameterizers.isotropic_gaussian import EPS_TOL, IsotropicGaussian
+from .reparameterizers.isotropic_gaussian import IsotropicGaussian
 
 
 def clamp_variance(logits, config, reparameterizer=None):
@@ -91,20 +91,7 @@ def kld(reparameterizer, dist, config):
     return reparameterizer.kl(dist['posterior'], dist['prior']) + prior_kl
 
 
-def loss_function_aggregate(step_losses):
-    """vrnn.py:767-803 (_add_loss_map + _mean_map) on already computed per-step dicts."""
-    agg = None
-    for lt in step_losses:
-        if agg is None:
-            agg = {**lt, 'count': 1}
-            continue
-        for k, v in lt.items():
-            agg[k] = agg[k] + v
-        agg['count'] += 1
-    for k in agg.keys():
-        if k != 'count':
-            agg[k] = agg[k] / agg['count']
-    return agg
+loss_function_aggregate = vrnn_loss_function   # vrnn.py:767-803 on already computed per-step dicts (one implementation: vae_amd.elbo)
 
 
 def loss_function(reparameterizer, config, recon_x, x, params, K=1, kl_beta=None, additive=False, inv_count=None):
@@ -118,16 +105,23 @@ def loss_function(reparameterizer, config, recon_x, x, params, K=1, kl_beta=None
         if additive:
             recon_x = [recon_x[-1] for _ in range(T)]
     B = recon_x[0].shape[0]
-    klds = torch.cat([kld(reparameterizer, p, config) for p in params], 0)            # [T*B]
-    recon_all = torch.cat([r.reshape(B, -1) for r in recon_x], 0)                      # [T*B, D or 2D]
-    x_all = torch.cat([xi.reshape(B, -1) for xi in x], 0)
+    klds = torch.cat([kld(reparameterizer, p, config) for p in params], 0)            # [T*B]: 4 bytes per step and sample
     kl_beta = config['kl_beta'] if kl_beta is None else kl_beta
     if inv_count is None:
         inv_count = 1.0 / (T * B)
     else:
         inv_count = inv_count / T
-    _, loss, elbo, means = F_.nll_elbo(x_all, recon_all, config['nll_type'], kld=klds, kl_beta=kl_beta,
-                                       inv_count=inv_count)
-    out = _pack(loss.view(T, B).mean(0), elbo.view(T, B).mean(0), means, kl_beta, loss.dtype)
+    if T <= F_.MAX_STEPS:
+        # the T reconstructions and targets are read where the decoder / the loader left them (pointer tables in the
+        # kernel arguments); the per-sample averages over the steps come out of the closing launch
+        _, _, _, means, loss_avg, elbo_avg = F_.nll_steps_elbo(list(x), list(recon_x), config['nll_type'], kld=klds,
+                                                               kl_beta=kl_beta, inv_count=inv_count)
+        out = _pack(loss_avg, elbo_avg, means, kl_beta, loss_avg.dtype)
+    else:
+        recon_all = torch.cat([r.reshape(B, -1) for r in recon_x], 0)                  # [T*B, D or 2D]
+        x_all = torch.cat([xi.reshape(B, -1) for xi in x], 0)
+        _, loss, elbo, means = F_.nll_elbo(x_all, recon_all, config['nll_type'], kld=klds, kl_beta=kl_beta,
+                                           inv_count=inv_count)
+        out = _pack(loss.view(T, B).mean(0), elbo.view(T, B).mean(0), means, kl_beta, loss.dtype)
     out['count'] = T
     return out
