@@ -213,10 +213,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # HIP events around every launch of every 5th timed step (BENCH_EVENT_EVERY=n: every n-th).  Each record is a
-    # barrier packet on the stream: bracketing all four launches of EVERY step costs 24 us per 380 us step (measured:
-    # 172.7 M samples/s against 184.0 M with one bracketed step per run), a fifth of the steps 0.4 %.
-    every = max(1, int(os.environ.get('BENCH_EVENT_EVERY', '5')))
+    # Per-kernel durations: HIP events around every launch of every step of ONE extra region of K steps, run before the
+    # timed regions and kept out of `value` (an event record is a barrier packet: bracketing all four launches costs
+    # ~15 us of a 326 us step).  BENCH_EVENT_EVERY=n brackets every n-th step of that region only.
+    every = max(1, int(os.environ.get('BENCH_EVENT_EVERY', '1')))
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] if k % every == 0 else None
               for k in range(args.steps)]
 
@@ -226,15 +226,18 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # the bracketed region (kernel durations only)
+    fence()
+    for k in range(args.steps):
+        step(events[k])
     # R timed regions of exactly K steps, each fenced (barrier + synchronize) on both sides, MAX over ranks per region;
-    # the figure is the MEDIAN region (min / max beside it): one 7-18 ms sample is thin evidence.  The per-kernel
-    # events are recorded in the first region only.
+    # the figure is the MEDIAN region (min / max beside it): one 7-18 ms sample is thin evidence.
     region_ms = []
     for r in range(max(1, args.repeats)):
         fence()
         t0 = time.perf_counter()
         for k in range(args.steps):
-            step(events[k] if r == 0 else None)
+            step()
         fence()
         dtr = time.perf_counter() - t0
         if dist is not None:
@@ -247,10 +250,23 @@ def main():
     # per-kernel average durations from the HIP events recorded on the launch stream during the timed steps
     seg = {'gauss_reparam_kl_fwd': (0, 1), names[1]: (1, 2), names[2]: (3, 4), 'gauss_reparam_kl_bwd': (4, 5)}
     timed = [e for e in events if e is not None]
-    dur_ms = {n: sum(e[a].elapsed_time(e[b]) for e in timed) / len(timed) for n, (a, b) in seg.items()}
+    # median over the bracketed steps: an event record is a barrier packet, and the odd bracket that lands behind a
+    # host hiccup is not the kernel's duration (rocprofv3's kernel-trace averages for the same command are committed
+    # under profiles/ for comparison)
+    import statistics
+    dur_ms = {n: statistics.median(e[a].elapsed_time(e[b]) for e in timed) for n, (a, b) in seg.items()}
     sanity = float(scalars[0].item())
     if not (sanity == sanity):
         raise SystemExit('bench: loss_mean is NaN')
+
+    # SURVEY 8(d)'s other figure, the one "north_star"'s 1 -> 8 GPU scaling target is about: the WHOLE model step --
+    # stock encoder / decoder (the example's nn.Linear 784-512-2L / L-512-784 networks, Adam) around the drop-in
+    # latent + loss half, at the same C2 shapes, with everything that crosses ranks inside the timed region: the packed
+    # all-reduce of the loss scalars (vae_amd.dist.globalize_loss) and ONE flat all-reduce of the network gradients
+    # (vae_amd.dist.FlatGradients; RCCL over xGMI under the default backend).  Reported beside the hot-path figure.
+    whole_model = None
+    if not args.main_only:
+        whole_model = whole_model_leg(dev, x.view(B, C, H, W), B, world, fence, all_reduce if dist is not None else None)
 
     # the production form of the same step (the module classes' default): eps drawn inside the kernels from
     # Philox4x32-10 instead of read from HBM -- reported beside the main figure, never as `value`
@@ -261,10 +277,12 @@ def main():
             step()
         ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] if k % every == 0 else None
                for k in range(args.steps)]
+        for k in range(args.steps):
+            step(ev2[k])
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         for k in range(args.steps):
-            step(ev2[k])
+            step()
         torch.cuda.synchronize(dev)
         dt2 = time.perf_counter() - t1
         noise_arg[0] = ptr(noise)
@@ -273,7 +291,7 @@ def main():
                           'kernels': {}}
         for n, (a, b) in seg.items():
             t2e = [e for e in ev2 if e is not None]
-            ms = sum(e[a].elapsed_time(e[b]) for e in t2e) / len(t2e)
+            ms = statistics.median(e[a].elapsed_time(e[b]) for e in t2e)
             philox_variant['kernels'][n] = {'avg_ms': round(ms, 5), 'algorithmic_bytes': ab2[n],
                                             'frac': round(ab2[n] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
@@ -379,7 +397,8 @@ def main():
                        'global_batch': B * world, 'latent': L, 'pixels': D, 'parallelism': 'dp%d' % world,
                        'noise': 'in-kernel Philox4x32-10' if philox else 'injected (resident in HBM)',
                        'logvar_output': 'materialized' if args.materialize_logvar else 'on first read (not written)',
-                       'kernel_timing': 'HIP events around each launch of %d of the %d timed steps' % (len(timed), args.steps)},
+                       'kernel_timing': 'HIP events around each launch of %d steps of an extra, bracketed region of %d steps '
+                                        '(not part of value), median' % (len(timed), args.steps)},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': kernels[dom]['achieved_GBs'],
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kernels[dom]['frac'], 'traffic': traffic},
             'kernels': kernels,
@@ -387,6 +406,7 @@ def main():
                          'achieved_GBs': round(total_bytes / (ksum * 1e-3) / 1e9, 1),
                          'frac': round(total_bytes / (ksum * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             'loss_mean': sanity,
+            'whole_model': whole_model,
             'module_path': module_path,
             'philox_variant': philox_variant,
             'stock_torch_same_gpu': stock_torch,
@@ -398,6 +418,53 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def whole_model_leg(dev, x_img, B, world, fence, all_reduce_max, steps=10, warmup=3):
+    import torch.distributed as tdist
+    sys.path.insert(0, os.path.join(ROOT, 'examples'))
+    from train_simple_vae import SimpleVAE
+    from vae_amd import dist as vdist
+    config = {'reparam_type': 'isotropic_gaussian', 'continuous_size': 2 * L, 'nll_type': 'bernoulli', 'kl_beta': 1.0,
+              'cuda': True, 'half': False, 'continuous_mut_info': 0, 'discrete_mut_info': 0}
+    torch.manual_seed(0)                       # the same initial weights on every rank
+    model = SimpleVAE(config).to(dev).train()
+    if world > 1:
+        vdist.configure(model, B * world)
+    flat = vdist.FlatGradients(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+
+    def wstep():
+        recon, params = model(x_img)
+        loss = model.loss_function(recon, x_img, params)
+        if world > 1:
+            loss, _ = vdist.globalize_loss(loss)
+        flat.zero()
+        loss['loss_mean'].backward()
+        flat.all_reduce()
+        opt.step()
+        return loss['loss_mean']
+    for _ in range(warmup):
+        last = wstep()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = wstep()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        all_reduce_max(t, op=tdist.ReduceOp.MAX)
+        dt = float(t.item())
+    val = float(last)
+    grad_bytes = flat.nbytes
+    del model, flat, opt
+    torch.cuda.empty_cache()
+    return {'ms_per_step': round(dt / steps * 1e3, 4), 'samples_per_s': B * world * steps / dt, 'steps': steps,
+            'allreduce_bytes_per_step': {'gradients': grad_bytes, 'loss_scalars': 6 * 4},
+            'loss_mean': val,
+            'what': 'example SimpleVAE (nn.Linear 784-512-%d / %d-512-784, Adam) fwd + loss + bwd + flat gradient '
+                    'all-reduce + optimizer step, B=%d per GPU, %d GPU(s)' % (2 * L, L, B, world)}
 
 
 def stock_torch_step_rate(logits, noise, x, recon, gz, steps=10):

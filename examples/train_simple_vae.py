@@ -7,11 +7,14 @@ half comes from vae_amd (ELBOMixin + a reparameterizer class from the registry).
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 \
         examples/train_simple_vae.py --steps 50                         # one process per GPU, RCCL
 
-Multi-GPU: every rank owns B rows of the global batch (EXAMPLE_BACKEND=gloo rehearses the same wiring with several
-ranks on one GPU, summing gradients through vae_amd.dist instead of DDP).  vae_amd.dist.configure() points the reparameterizer at
-its shard (global row offset for the in-kernel Philox draws, 1/B_global scaling of the batch means);
-globalize_loss() is the one packed all-reduce of the loss scalars; DDP averages the network gradients, so the
-loss that is backpropagated is multiplied by world_size (the kernels already divide by B_global)."""
+Multi-GPU: every rank owns B rows of the global batch.  vae_amd.dist.configure() points the reparameterizer at its
+shard (global row offset for the in-kernel Philox draws, 1/B_global scaling of the batch means); globalize_loss() is
+the one packed all-reduce of the loss scalars; the network gradients live in ONE flat buffer (vae_amd.dist.
+FlatGradients) that is summed over ranks as one message after backward -- the kernels already divide by B_global, so
+the sum IS the global-batch gradient.  The code path is the same under RCCL (the default, one GPU per rank) and under
+EXAMPLE_BACKEND=gloo (several ranks rehearsing on one GPU): only the collective underneath differs.  --ddp swaps the
+flat buffer for torch's DistributedDataParallel (bucketed, overlapped with backward; RCCL only -- it averages, so the
+loss is multiplied by world_size)."""
 import argparse
 import os
 import sys
@@ -48,6 +51,7 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--batch', type=int, default=4096, help='rows per GPU')
     ap.add_argument('--latent', type=int, default=64)
+    ap.add_argument('--ddp', action='store_true', help="torch DDP instead of vae_amd.dist.FlatGradients (RCCL only)")
     args = ap.parse_args()
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     # EXAMPLE_BACKEND=gloo lets several ranks share one GPU (a rehearsal of the wiring on a one-GPU box)
@@ -64,11 +68,14 @@ def main():
     torch.manual_seed(0)
     model = SimpleVAE(config).to(dev).train()
     net = model
-    ddp = world > 1 and backend == 'nccl'
+    ddp = world > 1 and args.ddp
+    if ddp and backend != 'nccl':
+        raise SystemExit('--ddp needs one GPU per rank over RCCL (EXAMPLE_BACKEND=nccl)')
     if world > 1:
         vdist.configure(model, args.batch * world)
     if ddp:
         net = nn.parallel.DistributedDataParallel(model, device_ids=[dev.index])
+    flat = None if ddp else vdist.FlatGradients(model.parameters())
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
     proto = (torch.rand(16, 1, 28, 28, generator=gen, device=dev) < 0.15).float()      # 16 "digit" prototypes
@@ -81,20 +88,13 @@ def main():
         loss = model.loss_function(recon, x, params)
         if world > 1:
             loss, _ = vdist.globalize_loss(loss)
-        opt.zero_grad(set_to_none=True)
         if ddp:      # DDP averages the per-rank gradients; they have to SUM to the global-batch gradient
+            opt.zero_grad(set_to_none=True)
             (loss['loss_mean'] * world).backward()
         else:
+            flat.zero()
             loss['loss_mean'].backward()
-            if world > 1:
-                # rehearsal backend: sum the per-rank gradients as one flat message through vae_amd.dist, which stages
-                # gloo traffic through the host (DDP's gloo reduction of device tensors stalls when ranks share a GPU)
-                grads = [p.grad for p in model.parameters()]
-                flat = vdist.all_reduce_inplace(torch.cat([g_.reshape(-1) for g_ in grads]))
-                o = 0
-                for g_ in grads:
-                    g_.copy_(flat[o:o + g_.numel()].view_as(g_))
-                    o += g_.numel()
+            flat.all_reduce()       # identity on one rank
         opt.step()
         if rank == 0 and (step % 10 == 0 or step == args.steps - 1):
             print('step %4d  loss %.3f  nll %.3f  kld %.3f' % (step, float(loss['loss_mean']), float(loss['nll_mean']),

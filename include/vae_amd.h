@@ -55,7 +55,7 @@ int vae_abi_version(void);
 /* Bytes of scratch every entry point that takes `workspace` may use. */
 size_t vae_workspace_bytes(void);
 /* Tuning hook (no reference counterpart; scripts/ab.py): overrides one launch-geometry choice for the calls that
- * follow, process-wide.  name: "G", "U", "MAXGRID" (the VAE_AMD_<name> environment variables set the same knobs
+ * follow, process-wide.  name: "G", "U", "MAXGRID", "REDUCEGRID" (the VAE_AMD_<name> environment variables set the same knobs
  * once, at the first launch); value 0 restores the built-in choice.  Results do not depend on any of them beyond
  * the summation order of the batch means.                                                         */
 int vae_tuning_set(const char* name, int64_t value);

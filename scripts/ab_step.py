@@ -2,7 +2,7 @@
 under several settings of the launch-geometry knobs, interleaved in ONE process (vae_tuning_set); VAE_AMD_LIB selects
 a variant build of the library (scripts/build_variant.sh) for the whole run.
 
-    python scripts/ab_step.py [variants=U:G:MAXGRID,...] [B=65536] [L=512] [D=784] [rounds=6] [steps=30]
+    python scripts/ab_step.py [variants=U:G:MAXGRID:REDUCEGRID,...] [B=65536] [L=512] [D=784] [rounds=6] [steps=30]
 
 Per variant: median whole-step time (no events inside the loop) and, from a second pass with HIP events around each
 launch, the median duration of the two reducing calls (gauss fwd, one-pass NLL; the closing launch of RMODE 2 is
@@ -41,7 +41,7 @@ inv, ms = 1.0 / B, 1.0 / (B * L)
 
 
 def setv(v):
-    for n, val in zip((b'U', b'G', b'MAXGRID'), tuple(v) + (0,) * (3 - len(v))):
+    for n, val in zip((b'U', b'G', b'MAXGRID', b'REDUCEGRID'), tuple(v) + (0,) * (4 - len(v))):
         assert lib.vae_tuning_set(n, val) == 0
 
 

@@ -113,3 +113,70 @@ def test_single_process_is_identity():
     a, b = torch.tensor(1.5), torch.arange(3.)
     x, y = packed_all_reduce([a, b])
     assert x is a and y is b
+
+
+def _grad_worker(rank, world, port, outdir):
+    """A tiny encoder -> (oracle) Gaussian latent + Bernoulli loss -> decoder model on this rank's rows: the flat
+    gradient buffer summed over ranks must be the single-process gradient of the global batch."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from vae_amd import dist as VD
+    torch.manual_seed(1)
+    Bg, L, Dp = 23, 4, 16
+    enc, dec = torch.nn.Linear(Dp, 2 * L), torch.nn.Linear(L, Dp)
+    x = (torch.rand(Bg, Dp) < 0.4).float()
+    noise = torch.randn(Bg, L)
+    row0, rows = VD.shard_rows(Bg)
+    sl = slice(row0, row0 + rows)
+    flat = VD.FlatGradients(list(enc.parameters()) + list(dec.parameters()))
+    for _ in range(2):              # twice: the second pass must not see the first pass's sums
+        flat.zero()
+        z, params = O.gauss_forward(enc(x[sl]), noise[sl])
+        local = _local_loss(O.nll(x[sl], dec(z), 'bernoulli'), O.gauss_kl(params), 1.0, 1.0 / Bg)
+        out, _ = VD.globalize_loss(local)
+        out['loss_mean'].backward()
+        flat.all_reduce()
+    assert all(p.grad.untyped_storage().data_ptr() == flat.flat.untyped_storage().data_ptr() for p in flat.params)
+    torch.save((flat.flat.clone(), out['loss_mean'].detach()), os.path.join(outdir, 'g%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradients_two_ranks_equal_one_rank(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = [torch.load(os.path.join(str(tmp_path), 'g%d.pt' % r), weights_only=True) for r in range(world)]
+    torch.manual_seed(1)
+    Bg, L, Dp = 23, 4, 16
+    enc, dec = torch.nn.Linear(Dp, 2 * L), torch.nn.Linear(L, Dp)
+    x = (torch.rand(Bg, Dp) < 0.4).float()
+    noise = torch.randn(Bg, L)
+    z, params = O.gauss_forward(enc(x), noise)
+    ref = O.loss_function(O.nll(x, dec(z), 'bernoulli'), O.gauss_kl(params), 1.0)
+    ref['loss_mean'].backward()
+    want = torch.cat([p.grad.reshape(-1) for p in list(enc.parameters()) + list(dec.parameters())])
+    for flat, loss_mean in res:
+        torch.testing.assert_close(flat, want, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(loss_mean, ref['loss_mean'].detach(), rtol=1e-5, atol=1e-5)
+
+
+def test_flat_gradients_refuses_replaced_grads():
+    import pytest
+    from vae_amd import dist as VD
+    lin = torch.nn.Linear(3, 2)
+    flat = VD.FlatGradients(lin.parameters())
+    assert flat.nbytes == 4 * (6 + 2)
+    lin(torch.randn(5, 3)).sum().backward()
+    assert float(flat.flat.abs().sum()) > 0
+    flat.zero()
+    assert float(flat.flat.abs().sum()) == 0
+    lin.zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError):
+        flat.zero()

@@ -16,6 +16,7 @@ int vae_tuning_set(const char* name, int64_t value) {
   if (!strcmp(name, "G")) k.G = (int)value;
   else if (!strcmp(name, "U")) k.U = (int)value;
   else if (!strcmp(name, "MAXGRID")) k.maxgrid = value;
+  else if (!strcmp(name, "REDUCEGRID")) k.reducegrid = (int)value;
   else return VAE_ERR_ARG;
   return VAE_OK;
 }

@@ -577,6 +577,7 @@ struct Knobs {
   int G = 0;            // VAE_AMD_G        lanes per row
   int U = 0;            // VAE_AMD_U        row-chunks in flight per lane
   int64_t maxgrid = 0;  // VAE_AMD_MAXGRID  grid cap
+  int reducegrid = 0;   // VAE_AMD_REDUCEGRID  grid of the kernels that close batch scalars with grid_reduce
 };
 inline Knobs& knobs() {
   static Knobs k = [] {
@@ -584,6 +585,7 @@ inline Knobs& knobs() {
     if (const char* e = getenv("VAE_AMD_G")) r.G = atoi(e);
     if (const char* e = getenv("VAE_AMD_U")) r.U = atoi(e);
     if (const char* e = getenv("VAE_AMD_MAXGRID")) r.maxgrid = atoll(e);
+    if (const char* e = getenv("VAE_AMD_REDUCEGRID")) r.reducegrid = atoi(e);
     return r;
   }();
   return k;
@@ -619,6 +621,7 @@ inline RowGeom row_geom(int64_t rows, int64_t vecs_per_row, int64_t max_grid = k
   if (kn.U == 1 || kn.U == 2 || kn.U == 4) g.U = kn.U;
   if (kn.maxgrid >= 1)
     max_grid = (max_grid <= kReduceGridMax && kn.maxgrid > kReduceGridMax) ? kReduceGridMax : kn.maxgrid;
+  if (max_grid == kGridReduce && kn.reducegrid >= 1 && kn.reducegrid <= kReduceGridMax) max_grid = kn.reducegrid;
   g.rows_per_block = kBlock / G;
   g.tiles = (rows + g.rows_per_block - 1) / g.rows_per_block;
   g.grid = (int)(g.tiles < max_grid ? g.tiles : max_grid);

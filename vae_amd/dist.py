@@ -9,9 +9,12 @@ ranges and no data-path collective exists.  What does cross ranks:
     over ranks IS the global-batch mean; the backward needs no communication.
   * the Flow "KL" cross-batch mean (flow.py:78 / SURVEY Q6): one extra float, all-reduced between
     the kernel's two phases (`reduce_fn`).
-  * gradients of the stock encoder / decoder parameters: the host project's DDP (not here).  With
-    1/B_global scaling the per-rank gradients SUM to the exact global-batch gradient; under DDP's
-    mean reduction multiply the loss by `world_size`.
+  * gradients of the stock encoder / decoder parameters: `FlatGradients` below -- every parameter's
+    .grad is a view of ONE flat buffer, all-reduced (sum) in place as one message after backward
+    (the VAE networks are a few MB, so one flat bucket beats many: the reduction is
+    latency-bound on xGMI) -- or the host project's DDP.  With 1/B_global scaling the per-rank
+    gradients SUM to the exact global-batch gradient; under DDP's mean reduction multiply the loss
+    by `world_size`.
 
 Noise: in-kernel Philox is keyed by the GLOBAL row index (`row_offset`), so an N-rank run draws
 exactly what the 1-rank run draws for the same rows.
@@ -76,6 +79,44 @@ def all_reduce_inplace(t, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         _sum_over_ranks_(t, group)
     return t
+
+
+class FlatGradients(object):
+    """One flat gradient buffer for a set of parameters: `p.grad` of every parameter is a view into it (autograd
+    accumulates into an existing .grad in place), so the cross-rank sum is ONE all-reduce of the buffer where it
+    lies -- no bucketing, no copies, the same code under RCCL ('nccl') and under gloo (CPU tests, several ranks
+    rehearsing on one GPU: staged through the host by _sum_over_ranks_).
+
+        flat = FlatGradients(model.parameters())
+        ... flat.zero(); loss.backward(); flat.all_reduce(); optimizer.step()      # never zero_grad(set_to_none=True)
+    """
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        assert self.params, "no parameters that require a gradient"
+        p0 = self.params[0]
+        sizes = [p.numel() for p in self.params]
+        self.flat = torch.zeros(sum(sizes), dtype=p0.dtype, device=p0.device)
+        o = 0
+        for p, n in zip(self.params, sizes):
+            assert p.dtype == p0.dtype and p.device == p0.device, "one dtype and device per FlatGradients"
+            p.grad = self.flat[o:o + n].view_as(p)
+            o += n
+
+    @property
+    def nbytes(self):
+        return self.flat.numel() * self.flat.element_size()
+
+    def zero(self):
+        for p in self.params:       # somebody replaced a view (zero_grad(set_to_none=True), a fresh .grad): put it back
+            if p.grad is None or p.grad.untyped_storage().data_ptr() != self.flat.untyped_storage().data_ptr():
+                raise RuntimeError("FlatGradients: a parameter's .grad no longer aliases the flat buffer "
+                                   "(use flat.zero(), not zero_grad(set_to_none=True))")
+        self.flat.zero_()
+
+    def all_reduce(self, group=None):
+        """Sum over ranks, in place; identity when not distributed."""
+        return all_reduce_inplace(self.flat, group)
 
 
 def configure(module, global_batch, rank=None, world_size=None, group=None):
