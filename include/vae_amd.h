@@ -60,6 +60,20 @@ size_t vae_workspace_bytes(void);
  * the summation order of the batch means.                                                         */
 int vae_tuning_set(const char* name, int64_t value);
 
+/* "Saw a NaN" word (replaces the per-step host check nan_check_and_break of abstract_vae.py:366-369,
+ * isotropic_gaussian.py:89-90, vrnn.py:427-428, which synchronises the stream on every step).  The closing wave of
+ * every kernel that finishes batch means ORs VAE_NAN_* bits into one word of `workspace` when a mean comes out NaN
+ * (one NaN sample makes its batch sum NaN): no extra traffic, no synchronisation.  The word is sticky.
+ * vae_nan_flag copies it to *flags_out (host memory) after the work queued on `stream` so far has finished -- it
+ * synchronises `stream`: call it once per epoch / every N steps, not per step -- and, with clear != 0, zeroes it.
+ * vae_nll_elbo_fused_static keeps the word of its built-in scratch (pass workspace = NULL here to read that one;
+ * the device that owns `stream` must be current).                                                            */
+enum { VAE_NAN_NLL = 1,     /* nll / loss / elbo means (the decoder's output or the target held a NaN / inf-inf) */
+       VAE_NAN_KLD = 2,     /* kld mean */
+       VAE_NAN_LATENT = 4,  /* a reparameterizer's parameter means (mu / logvar, concentrations): NaN in the encoder logits */
+       VAE_NAN_OTHER = 8 }; /* additional-loss / mutual-information means, the Flow "KL" mean */
+int vae_nan_flag(float* workspace, int clear, uint32_t* flags_out, vae_stream_t stream);
+
 /* ---- IsotropicGaussian ------------------------------------------------------
  * reparameterizers/isotropic_gaussian.py:98-131 (split + eps_tol), :77-96
  * (z = e*(0.5*s) + mu, NO exp; eval: z = mu), :158-170 (KL vs N(0,1)),

@@ -57,11 +57,10 @@ variants = list(itertools.product(libs, knobs['G'], knobs['U'], knobs['MAXGRID']
 
 
 def setenv(G, U, MG):
-    for k, v in (('VAE_AMD_G', G), ('VAE_AMD_U', U), ('VAE_AMD_MAXGRID', MG)):
-        if v == 'auto':
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+    """The knobs are read from the environment once per library; in-process changes go through vae_tuning_set."""
+    for lib in handles.values():
+        for k, v in ((b'G', G), (b'U', U), (b'MAXGRID', MG)):
+            lib.vae_tuning_set(k, 0 if v == 'auto' else int(v))
 
 
 names = [n for n in kernels(handles[libs[0]]) if not only or n in only]

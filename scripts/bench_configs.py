@@ -2,8 +2,12 @@
 
     python scripts/bench_configs.py [--json out.json]
 
-Every kernel is called through the C ABI on preallocated buffers; time = HIP events around 20
-back-to-back launches after 5 warm-ups; bytes = algorithmic bytes of that launch.
+Every kernel is called through the C ABI on preallocated buffers; bytes = algorithmic bytes of that
+launch.  Time: launches that move >= 32 MB are timed ONE AT A TIME with HIP events, each behind a 512 MiB fill of
+another buffer, median of 9 -- the caches are then as cold as the kernels of a training step find them (r02: looping
+one kernel on its own working set let the 256 MiB Infinity Cache hold part of it, which flattered plain stores and
+hid what non-temporal stores gain; --loop restores that form).  Smaller launches (latency-bound): HIP events around 20
+back-to-back launches after 5 warm-ups.
 """
 import argparse
 import ctypes
@@ -30,17 +34,35 @@ def T(*shape, dtype=torch.float32, kind='randn'):
     return torch.empty(*shape, device=dev, dtype=dtype)
 
 
+LOOP = '--loop' in sys.argv
+_flush = None
+
+
 def timeit(name, cfg, fn, nbytes, iters=20):
+    global _flush
     for _ in range(5):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    if nbytes >= (32 << 20) and not LOOP:
+        if _flush is None:
+            _flush = torch.empty(512 << 18, device=dev)      # 512 MiB of fp32
+        samples = []
+        for _ in range(9):
+            _flush.fill_(1.0)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            samples.append(e0.elapsed_time(e1))
+        ms = sorted(samples)[len(samples) // 2]
+    else:
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
     gbs = nbytes / ms / 1e6
     rows.append({'kernel': name, 'config': cfg, 'ms': round(ms, 5), 'algorithmic_MB': round(nbytes / 1e6, 1),
                  'GBs': round(gbs), 'frac_of_8TBs': round(gbs / 8000, 3)})
@@ -55,8 +77,11 @@ def gauss(B, L, dtype=torch.float32, philox=False):
     gl, means = T(B, 2 * L, dtype=dtype, kind='e'), torch.zeros(2, device=dev)
     n = None if philox else noise
     cfg = 'B=%d L=%d %s%s' % (B, L, 'bf16' if dc else 'f32', ' philox' if philox else '')
-    timeit('gauss_reparam_kl_fwd', cfg, lambda: call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, ptr(n), ptr(z), 0, ptr(lv), ptr(kl), ptr(means), ptr(ws), B, L, 1e-6, 1.0 / (B * L), 1, 1, 1, 0, dc, st),
-           B * ((4 if philox else 5) * L * es + es) - B * L * es)  # SURVEY figure: logits + noise + z + kl (logvar write not counted)
+    # the training-step form: logvar is produced on first read (vae_amd/lazy.py), the launch writes z and kl
+    timeit('gauss_reparam_kl_fwd', cfg, lambda: call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, ptr(n), ptr(z), 0, None, ptr(kl), ptr(means), ptr(ws), B, L, 1e-6, 1.0 / (B * L), 1, 1, 1, 0, dc, st),
+           B * ((3 if philox else 4) * L * es + es))
+    timeit('gauss_reparam_kl_fwd', cfg + ' +logvar', lambda: call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, ptr(n), ptr(z), 0, ptr(lv), ptr(kl), ptr(means), ptr(ws), B, L, 1e-6, 1.0 / (B * L), 1, 1, 1, 0, dc, st),
+           B * ((4 if philox else 5) * L * es + es))
     timeit('gauss_reparam_kl_bwd', cfg, lambda: call('vae_gauss_reparam_kl_bwd', ptr(logits), 2 * L, ptr(n), ptr(gz), 0, None, ptr(gkl), None, ptr(gl), 0, B, L, 1e-6, 1.0 / (B * L), 1, 1, 1, 0, dc, st),
            B * ((5 if philox else 6) * L * es + es))
 
@@ -267,6 +292,7 @@ def graph_step(B, L):
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--json', default=None)
+    ap.add_argument('--loop', action='store_true', help='time every launch as a back-to-back loop (warm caches)')
     args = ap.parse_args()
     print('== C2 family: IsotropicGaussian + Bernoulli NLL sweeps')
     for B, L in [(4096, 32), (16384, 128), (65536, 512), (65536, 1024)]:

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the CDLL below, see module 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VAE_AMD_LIB') or os.path.join(_HERE, 'libvae_amd.so')  # env override: tuning builds only
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 VAE_OK, VAE_ERR_ARG, VAE_ERR_LAUNCH = 0, 1, 2
 VAE_F32, VAE_BF16, VAE_F16 = 0, 1, 2
@@ -27,6 +27,7 @@ _pp = ctypes.POINTER(ctypes.c_void_p)   # host array of device pointers
 SIGNATURES = {
     'vae_abi_version': [],
     'vae_workspace_bytes': [],
+    'vae_nan_flag': [_p, _i, ctypes.POINTER(ctypes.c_uint32), _p],
     'vae_tuning_set': [ctypes.c_char_p, _i64],
     'vae_gauss_reparam_kl_fwd': [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i64, _i64, _f, _f, _i, _u64, _u64, _i64, _i,
                                  _p],
@@ -165,6 +166,33 @@ def workspace(device):
         ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)  # zeroed once: ticket counters
         _workspaces[key] = ws
     return ws
+
+
+NAN_BITS = {1: 'nll / loss / elbo', 2: 'kld', 4: 'reparameterizer parameters (encoder logits)',
+            8: 'additional loss / mutual information / flow KL'}
+
+
+def nan_flags(device=None, clear=True):
+    """OR of the sticky saw-a-NaN words (include/vae_amd.h: VAE_NAN_*) of every workspace this process holds on
+    `device` (default: the current one).  Synchronises the streams those workspaces belong to: meant for the end of
+    an epoch or every N steps -- the kernels raise the bits without any host involvement (the reference's
+    nan_check_and_break, abstract_vae.py:366-369, synchronises on every step instead)."""
+    index = torch.cuda.current_device() if device is None else torch.device(device).index
+    index = torch.cuda.current_device() if index is None else index
+    flags = 0
+    out = ctypes.c_uint32(0)
+    with torch.cuda.device(index):
+        for (dev_index, stream), ws in list(_workspaces.items()):
+            if dev_index != index:
+                continue
+            call('vae_nan_flag', ctypes.c_void_p(ws.data_ptr()), int(bool(clear)), ctypes.byref(out),
+                 ctypes.c_void_p(stream))
+            flags |= out.value
+    return flags
+
+
+def describe_nan_flags(flags):
+    return ', '.join(name for bit, name in NAN_BITS.items() if flags & bit)
 
 
 def call(name, *args):

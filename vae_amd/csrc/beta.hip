@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kBlock) void beta_split_fwd_kernel(
     klr = group_sum(klr, G);
     if (row < B && sub == 0) kl[row] = from_f32<T>(klr);
   }
-  if (ws) grid_reduce<2>(acc, ws, mean_scale, means);
+  if (ws) grid_reduce<2>(acc, ws, mean_scale, means, kNanGauss2);
 }
 
 // glogits = sigmoid' * (g_conc + gkl * dKL/dconc + g_mean * mean_scale)

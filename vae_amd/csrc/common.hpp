@@ -352,7 +352,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // 13 us tail at 1024 blocks, measured), so blocks draw from kTicketFan sub-counters on separate
 // 64-byte lines and only the last block of each sub-counter draws from the master counter.
 // Workspace layout (floats): [0,16) master counter | [16*(1+s), ...) sub-counter s (one per 64 B)
-// | [1024, 1024 + kReduceGridMax*8) bpart.
+// | [kWsNanFlag] the sticky saw-a-NaN word | [1024, 1024 + kReduceGridMax*8) bpart.
 // ---------------------------------------------------------------------------------------------
 constexpr int kReduceGridMax = 2048;
 constexpr int kTicketFan = 32;
@@ -365,9 +365,25 @@ __device__ __forceinline__ float shared_load(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// "Saw a NaN" word of a workspace (float index kWsNanFlag, read as uint32): the closing wave of every kernel that
+// finishes batch means ORs a bit in when a mean comes out NaN -- a NaN in any sample's nll / kld / latent
+// parameter makes its batch sum NaN -- so the host can look at one word at the end of an epoch instead of
+// synchronising on every step as the reference's nan_check_and_break does (abstract_vae.py:366-369,
+// isotropic_gaussian.py:89-90, vrnn.py:427-428).  Sticky until the caller clears it.  `nanbits`: 4 bits per
+// output slot, the VAE_NAN_* bit(s) that slot raises.
+constexpr int kWsNanFlag = 600;
+constexpr uint32_t kNanElbo6 = 0x882111u;   // loss, elbo, nll -> VAE_NAN_NLL | kld -> VAE_NAN_KLD | add, mi -> VAE_NAN_OTHER
+constexpr uint32_t kNanGauss2 = 0x44u;      // the two latent-parameter means -> VAE_NAN_LATENT
+__device__ __forceinline__ void note_nan(float* __restrict__ ws, float value, uint32_t nanbits, int slot) {
+  const uint32_t bits = (nanbits >> (4 * slot)) & 0xfu;
+  if (bits && value != value)
+    __hip_atomic_fetch_or(reinterpret_cast<unsigned int*>(ws + kWsNanFlag), bits, __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int N>
 __device__ __forceinline__ void grid_reduce(float (&acc)[N], float* __restrict__ ws, float scale,
-                                            float* __restrict__ out) {
+                                            float* __restrict__ out, uint32_t nanbits = 0) {
   static_assert(N <= 8, "at most 8 batch scalars per kernel");
   __shared__ float lds[kBlock / 64][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -388,6 +404,7 @@ __device__ __forceinline__ void grid_reduce(float (&acc)[N], float* __restrict__
     for (int w = 0; w < kBlock / 64; ++w) s += lds[w][lane];
     if (grid == 1) {
       out[lane] = s * scale;
+      note_nan(ws, s, nanbits, lane);
     } else {
       shared_store(&bpart[(size_t)blockIdx.x * 8 + lane], s);
     }
@@ -438,7 +455,10 @@ __device__ __forceinline__ void grid_reduce(float (&acc)[N], float* __restrict__
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const double x = wave_sum_d(v[k]);
-    if (lane == 0) out[k] = (float)(x * (double)scale);
+    if (lane == 0) {
+      out[k] = (float)(x * (double)scale);
+      note_nan(ws, (float)x, nanbits, k);
+    }
   }
   if (lane == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -449,7 +469,7 @@ __device__ __forceinline__ void grid_reduce(float (&acc)[N], float* __restrict__
 // order by the block that arrives last.  Same hand-off as grid_reduce.  Every thread of the block calls it.
 template <int N>
 __device__ __forceinline__ void close_block_sums_d(double (&v)[N], float* __restrict__ ws, float scale,
-                                                   float* __restrict__ out) {
+                                                   float* __restrict__ out, uint32_t nanbits = 0) {
   __shared__ double ldsd[kBlock / 64][8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -466,7 +486,10 @@ __device__ __forceinline__ void close_block_sums_d(double (&v)[N], float* __rest
   }
   const int grid = gridDim.x;
   if (grid == 1) {
-    if (lane < N) out[lane] = (float)(mine * (double)scale);
+    if (lane < N) {
+      out[lane] = (float)(mine * (double)scale);
+      note_nan(ws, (float)mine, nanbits, lane);
+    }
     return;
   }
   unsigned int* master = reinterpret_cast<unsigned int*>(ws);
@@ -485,7 +508,10 @@ __device__ __forceinline__ void close_block_sums_d(double (&v)[N], float* __rest
   for (int k = 0; k < N; ++k) {
     double x = lane < grid ? cpart[(size_t)lane * 8 + k] : 0.0;
     x = wave_sum_d(x);
-    if (lane == 0) out[k] = (float)(x * (double)scale);
+    if (lane == 0) {
+      out[k] = (float)(x * (double)scale);
+      note_nan(ws, (float)x, nanbits, k);
+    }
   }
   if (lane == 0) __hip_atomic_store(master, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void elbo_combine_fwd_kernel(
     elbo[row] = from_f32<T>(e);
     acc[0] += l; acc[1] += e; acc[2] += n; acc[3] += k; acc[4] += ad; acc[5] += m;
   }
-  if (ws) grid_reduce<6>(acc, ws, inv_count, means);
+  if (ws) grid_reduce<6>(acc, ws, inv_count, means, kNanElbo6);
 }
 
 template <typename T>
@@ -414,7 +414,7 @@ static int nll_fwd_dispatch(const void* x, const void* recon, const void* kld, c
                             float kl_beta, float inv_count, hipStream_t stream) {
   constexpr int VN = VecOf<T>::n;
   const bool vec = (D % VN == 0) && aligned16(x) && aligned16(recon);
-  const RowGeom g = nll_geom(B, vec ? D / VN : D, kGridStream);
+  const RowGeom g = nll_geom(B, vec ? D / VN : D, kGridStream, false, true);
   const FlatRows<T> src{(const T*)x, (const T*)recon, nullptr, B};
   nll_fwd_launch<T, NLL>(src, vec, g, g.tiles, kld, add, mi, nll, loss, elbo, D, kl_beta, stream);
   if (loss && means) launch_rows_means<T>(loss, elbo, nll, kld, add, mi, workspace, inv_count, means, B, stream);
@@ -458,7 +458,7 @@ static int nll_steps_fwd_dispatch(const void* const* xs, const void* const* reco
   bool al = true;
   if (!fill_steps(&src.tab, xs, recons, nullptr, steps, &al)) return VAE_ERR_ARG;
   const bool vec = (D % VN == 0) && al;
-  const RowGeom g = nll_geom(B * steps, vec ? D / VN : D, kGridStream);   // geometry by the whole launch
+  const RowGeom g = nll_geom(B * steps, vec ? D / VN : D, kGridStream, false, true);   // geometry by the whole launch
   src.B = B;
   src.tps = (B + g.rows_per_block - 1) / g.rows_per_block;                // tiles never straddle steps
   nll_fwd_launch<T, NLL>(src, vec, g, src.tps * steps, kld, nullptr, nullptr, nll, loss, elbo, D, kl_beta, stream);
@@ -677,10 +677,24 @@ int vae_nll_elbo_fused_static(const void* x, const void* recon, int nll_type, co
   const int rc = scratch_for_current_device(&ws);
   if (rc != VAE_OK) return rc;
   // The array keeps the last call's contents: the arrival counters must read zero when the closing launch starts
-  // (a completed call leaves them at zero; one that was cut short need not).
-  if (hipMemsetAsync(ws, 0, 1024 * sizeof(float), (hipStream_t)stream) != hipSuccess) return VAE_ERR_LAUNCH;
+  // (a completed call leaves them at zero; one that was cut short need not).  The saw-a-NaN word behind them stays.
+  if (hipMemsetAsync(ws, 0, vae::kWsNanFlag * sizeof(float), (hipStream_t)stream) != hipSuccess) return VAE_ERR_LAUNCH;
   return vae_nll_elbo_fused(x, recon, nll_type, kld, add, mi, kl_beta, inv_count, grad_scale, nll, loss, elbo, means,
                             ws, grecon, B, D, dtype, stream);
+}
+
+int vae_nan_flag(float* workspace, int clear, uint32_t* flags_out, vae_stream_t stream) {
+  if (!flags_out) return VAE_ERR_ARG;
+  float* ws = workspace;
+  if (!ws) {
+    const int rc = scratch_for_current_device(&ws);
+    if (rc != VAE_OK) return rc;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemcpyAsync(flags_out, ws + vae::kWsNanFlag, sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess)
+    return VAE_ERR_LAUNCH;
+  if (clear && hipMemsetAsync(ws + vae::kWsNanFlag, 0, sizeof(uint32_t), st) != hipSuccess) return VAE_ERR_LAUNCH;
+  return hipStreamSynchronize(st) == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 
 int vae_nll_fused_grad_finish(void* grecon, const float* gmeans, int64_t n, int dtype, vae_stream_t stream) {

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(kBlock) void flow_rows_kernel(const T* __restrict__
       acc[0] += v;
     }
   }
-  if (ws) grid_reduce<1>(acc, ws, inv_count, mean_out);
+  if (ws) grid_reduce<1>(acc, ws, inv_count, mean_out, 0x8u);
 }
 
 // 2-D: kl[i] = mean[0] - logdet[i].   3-D: kl[i] = rowval[i] - (1/R) sum_r logdet[i, r]

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void gauss_multi_fwd_kernel(
     klr = group_sum(klr, G);
     if (row < B && sub == 0) kl[row] = from_f32<T>(klr);
   }
-  if (ws) grid_reduce<2>(acc, ws, mean_scale, means);
+  if (ws) grid_reduce<2>(acc, ws, mean_scale, means, kNanGauss2);
 }
 
 // d mu = sum_s gz[s] + gkl*mu + gm;  d s = 0.5 sum_s e[s] gz[s] + gs + gkl (s - 1/s) + gm
@@ -348,7 +348,7 @@ static int nll_multi_fwd_dispatch(const void* x, const PtrPack& rp, bool al, int
                                   int64_t B, int64_t D, float kl_beta, float inv_count, hipStream_t st) {
   constexpr int VN = VecOf<T>::n;
   const bool vec = (D % VN == 0) && aligned16(x) && al;
-  const RowGeom g = nll_geom(B, vec ? D / VN : D, kGridStream);
+  const RowGeom g = nll_geom(B, vec ? D / VN : D, kGridStream, false, true);
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_multi_fwd_kernel<T, VN, NLL, U>), dim3(g.grid), dim3(kBlock), 0, st,
                                          (const T*)x, rp, S, (const T*)kld, (const T*)add, (const T*)mi, (T*)nll,

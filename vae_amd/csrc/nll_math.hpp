@@ -127,8 +127,20 @@ struct StepRows {
 // Long rows with few samples: give a row to the whole block so the chip stays full.
 // `long_rows_always`: the store-heavy backward of 3x64x64 rows measured 3-4 points faster block-per-row at any B
 // (fewer concurrent DRAM streams: 5 per block instead of 5 per wave); the forward is not (r01, B=8192).
-inline RowGeom nll_geom(int64_t B, int64_t vecs_per_row, int64_t max_grid, bool long_rows_always = false) {
+// `loads_only` (the forward kernels: nothing but [B] vectors is stored): rows of 65..128 vectors run two rows per wave
+// (G = 32, four chunks per lane) instead of one row per wave with a half-empty second chunk -- bf16 784-pixel rows
+// (98 vectors) 57.6 -> 67 % of peak (r02, scripts/ab.py); the store-heavy backward keeps the wave per row.
+inline RowGeom nll_geom(int64_t B, int64_t vecs_per_row, int64_t max_grid, bool long_rows_always = false,
+                        bool loads_only = false) {
   RowGeom g = row_geom(B, vecs_per_row, max_grid);
+  if (loads_only && g.G == 64 && vecs_per_row <= 128 && knobs().G == 0 && knobs().U == 0) {
+    g.G = 32;
+    g.U = 4;
+    g.rows_per_block = kBlock / g.G;
+    g.tiles = (B + g.rows_per_block - 1) / g.rows_per_block;
+    g.grid = (int)(g.tiles < max_grid ? g.tiles : max_grid);
+    if (g.grid < 1) g.grid = 1;
+  }
   if (vecs_per_row >= 1024 && (long_rows_always || g.tiles < 4 * 256)) {
     g.G = kBlock;
     g.U = 4;
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void elbo_rows_means_kernel(const T* __rest
     if (add) v[4] += (double)to_f32(add[row]);
     if (mi) v[5] += (double)to_f32(mi[row]);
   }
-  close_block_sums_d<6>(v, ws, inv_count, means);
+  close_block_sums_d<6>(v, ws, inv_count, means, kNanElbo6);
 }
 
 template <typename T>

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kBlock) void gauss_pair_fwd_kernel(
       if (kl_prior) kl_prior[row] = from_f32<T>(k0);
     }
   }
-  if (ws) grid_reduce<4>(acc, ws, mean_scale, means);
+  if (ws) grid_reduce<4>(acc, ws, mean_scale, means, kNanGauss2 | (kNanGauss2 << 8));
 }
 
 template <typename T, int V, int U>

@@ -89,6 +89,25 @@ class ELBOMixin(object):
 
     kl_annealer = None
     inv_count = None  # 1/B_global when the batch is sharded (vae_amd.dist)
+    _nan_check_calls = 0
+
+    def nan_check(self, force=False):
+        """The reference checks nll and kld for NaN on the host at every step (abstract_vae.py:366-369: one stream
+        synchronisation per step).  Here the closing wave of the kernels raises a sticky device bit when a batch mean
+        comes out NaN, at no cost; config['vae_amd_nan_check'] = N reads it every N-th loss_function call (one
+        synchronisation per N steps) and raises FloatingPointError naming what went NaN.  0 / absent: never read
+        (call model.nan_check(force=True) or vae_amd.nan_flags() at the end of an epoch)."""
+        every = int(self.config.get('vae_amd_nan_check', 0) or 0)
+        if not force:
+            if every <= 0:
+                return
+            self._nan_check_calls += 1
+            if self._nan_check_calls % every:
+                return
+        from ._lib import describe_nan_flags, nan_flags
+        flags = nan_flags(clear=True)
+        if flags:
+            raise FloatingPointError("vae_amd: NaN in " + describe_nan_flags(flags))
 
     def compute_kl_beta(self, kl_beta_list):
         if self.kl_annealer is not None:
@@ -144,8 +163,10 @@ class ELBOMixin(object):
         kld = self.kld(params)
         mi = self.mut_info(params, x.size(0))
         kl_beta = self.compute_kl_beta([self.config['kl_beta']])[0]
-        return loss_function(recon_x, x, kld, nll_type, kl_beta=kl_beta, mut_info=mi,
-                             extra_loss_terms=extra_loss_terms, inv_count=self.inv_count)
+        out = loss_function(recon_x, x, kld, nll_type, kl_beta=kl_beta, mut_info=mi,
+                            extra_loss_terms=extra_loss_terms, inv_count=self.inv_count)
+        self.nan_check()
+        return out
 
     def likelihood(self, loader, K=1000):
         """abstract_vae.py:281-317, quirks included: every sample is expanded to a batch of itself, drawn
