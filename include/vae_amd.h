@@ -313,13 +313,15 @@ int vae_nll_multi_elbo_bwd(const void* x, const void* const* recons, void* const
  * (a pointer may repeat: one target scored at every step), scored as one [steps * B] batch, step-major:
  *   kld [steps*B] (the per-step KL vectors, one after the other) or NULL;
  *   nll, loss, elbo [steps*B]: the per-step vectors;  loss_avg, elbo_avg [B]: their mean over the steps, summed
- *   step by step in the tensor dtype as the reference does;  means: 6 floats = sums * inv_count
- *   (inv_count = 1 / (steps * B_global): the mean over steps of the per-step means).
+ *   step by step in the tensor dtype as the reference does (both NULL: not wanted);  means: 6 floats = sums *
+ *   inv_count (inv_count = 1 / (steps * B_global): the mean over steps of the per-step means);
+ *   elbo_lse [B] or NULL: log-sum-exp over the steps of elbo -- AbstractVAE.likelihood's importance-sampling
+ *   estimate (abstract_vae.py:301-315) when the steps are `steps` decoded draws of each sample's posterior.
  * No counterpart launch structure in the reference: ~40 launches per step there.                              */
 int vae_nll_steps_elbo_fwd(const void* const* xs, const void* const* recons, int64_t steps, int nll_type,
                            const void* kld, float kl_beta, float inv_count, void* nll, void* loss, void* elbo,
-                           void* loss_avg, void* elbo_avg, float* means, float* workspace, int64_t B, int64_t D,
-                           int dtype, vae_stream_t stream);
+                           void* loss_avg, void* elbo_avg, void* elbo_lse, float* means, float* workspace, int64_t B,
+                           int64_t D, int dtype, vae_stream_t stream);
 /* grecons: HOST array of `steps` device pointers, each written with d / d recons[t] (a reconstruction that is
  * scored at several steps must be given distinct gradient buffers: the caller adds them up);  gnll, gloss,
  * gelbo [steps*B] (each may be NULL), gmeans 6 floats or NULL;  gkld [steps*B] or NULL.                       */

@@ -184,6 +184,53 @@ def multi(B, L, D, S):
            B * (4 * D + S * 8 * D))
 
 
+def likelihood(B, K, L=64, D=784):
+    """AbstractVAE.likelihood over one minibatch (abstract_vae.py:281-317): the batched form against the reference's
+    loop (selected by an overridden reparameterize), wall time of the whole call; decoder = one nn.Linear."""
+    import time
+    import torch.nn as nn
+    from vae_amd.elbo import ELBOMixin
+    from vae_amd.reparameterizers import IsotropicGaussian
+
+    def model(mixin):
+        class M(mixin, nn.Module):
+            def __init__(self):
+                nn.Module.__init__(self)
+                self.config = {'continuous_size': 2 * L, 'nll_type': 'bernoulli', 'kl_beta': 1.0, 'cuda': True,
+                               'half': False, 'continuous_mut_info': 0, 'discrete_mut_info': 0,
+                               'reparam_type': 'isotropic_gaussian'}
+                self.reparameterizer = IsotropicGaussian(self.config)
+                self.enc, self.dec = nn.Linear(D, 2 * L), nn.Linear(L, D)
+
+            def encode(self, x):
+                return self.enc(x)
+
+            def decode(self, z):
+                return self.dec(z)
+        torch.manual_seed(0)
+        m = M().to(dev).eval()
+        m.reparameterizer.train(True)
+        return m
+
+    class Loop(ELBOMixin):
+        def reparameterize(self, logits, labels=None, force=False):
+            return self.reparameterizer(logits, force=force)
+
+    x = (torch.rand(B, D, device=dev) < 0.3).float()
+    loader = [(x, torch.zeros(B, dtype=torch.long, device=dev))]
+    for name, mixin in (('likelihood (batched)', ELBOMixin), ('likelihood (reference loop)', Loop)):
+        m = model(mixin)
+        m.likelihood(loader, K=K)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        val = float(m.likelihood(loader, K=K))
+        ms = (time.perf_counter() - t0) * 1e3
+        draws = B * (K // B) * B
+        print('%-26s %-44s %9.2f ms  %d decoded draws, %.1f M draws/s, value %.3f' % (
+            name, 'B=%d K=%d L=%d %dpx bernoulli f32' % (B, K, L, D), ms, draws, draws / ms / 1e3, val), flush=True)
+        rows.append({'kernel': name, 'config': 'B=%d K=%d L=%d D=%d' % (B, K, L, D), 'ms': round(ms, 3), 'draws': draws})
+
+
 def bernoulli(B, K):
     logits, U, gy = T(B, K), T(B, K, kind='rand'), T(B, K)
     y, zh, gl, kl, gkl = T(B, K, kind='e'), T(B, K, kind='e'), T(B, K, kind='e'), T(B, kind='e'), T(B)
@@ -331,6 +378,7 @@ if __name__ == '__main__':
     print('== multi-sample forms (loss_function K > 1, MSGVAE, likelihood)')
     multi(65536, 512, 784, 4)
     multi(16384, 128, 784, 8)
+    likelihood(64, 1024)
     print('== Bernoulli / Beta reparameterizers')
     bernoulli(65536, 1024)
     beta(65536, 512)

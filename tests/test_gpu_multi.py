@@ -101,18 +101,84 @@ def test_msg_reparameterize_golden(golden):
     assert not torch.equal(za[0], za[1])
 
 
+def _draw_major(noises, B, P):
+    """The reference draws sample i's pass p as noises[i * P + p] ([B, L]: one row per replica of the sample);
+    the batched path wants [S = P * B, B, L], draw-major."""
+    L = noises[0].shape[-1]
+    out = torch.empty(P * B, B, L)
+    for i in range(B):
+        for p in range(P):
+            out[p * B:(p + 1) * B, i] = noises[i * P + p]
+    return out
+
+
+@pytest.mark.parametrize('path', ['batched', 'loop'])
 @pytest.mark.parametrize('name', ['multi_likelihood_draws', 'multi_likelihood_mean'])
-def test_likelihood_golden(golden, name):
+def test_likelihood_golden(golden, name, path):
+    """AbstractVAE.likelihood as the reference ran it (tests/golden/multi.pt) against both forms here: the batched
+    one (all draws of the minibatch from one logits read, one decoder call, log-sum-exp folded into the scoring
+    launch's closing kernel) and the reference's loop, which an overridden reparameterize() selects."""
     from vae_amd import elbo as E
     g = golden('multi')[name]
-    m = make_model(g, E.ELBOMixin).eval()
+    B, K = g['x'].shape[0], g['K']
+    mixin = E.ELBOMixin
+    if path == 'loop':
+        class mixin(E.ELBOMixin):
+            def reparameterize(self, logits, labels=None, force=False):
+                return self.reparameterizer(logits, force=force)
+    m = make_model(g, mixin).eval()
     m.reparameterizer.train(g['reparam_training'])
-    if g['reparam_training']:
+    loader = [(g['x'], torch.zeros(B).long())]
+    if not g['reparam_training']:
+        val = m.likelihood(loader, K=K)
+    elif path == 'loop':
         noises = iter([n.to(DEV) for n in g['noises']])
         fwd = m.reparameterizer.forward
         m.reparameterizer.forward = lambda lg, force=False, noise=None: fwd(lg, force=force, noise=next(noises))
-    val = m.likelihood([(g['x'], torch.zeros(g['x'].shape[0]).long())], K=g['K'])
+        val = m.likelihood(loader, K=K)
+    else:
+        val = m.likelihood(loader, K=K, noise=[_draw_major(g['noises'], B, K // B).to(DEV)])
     close(val, g['value'], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('rows', [1 << 16, 300, 7])     # one decoder call / sample groups / a lone sample in pieces
+def test_likelihood_batched_equals_loop_on_the_same_draws(rows):
+    """B = 12 samples, K = 150 -> 12 passes, S = 144 draws per sample (two scoring launches of <= 128 draws each,
+    combined), against the reference's loop fed the same noise; also a ragged last minibatch."""
+    from vae_amd import elbo as E
+
+    class Loop(E.ELBOMixin):
+        def reparameterize(self, logits, labels=None, force=False):
+            return self.reparameterizer(logits, force=force)
+
+    torch.manual_seed(5)
+    g = {'dec_weight': torch.randn(12, 4) * 0.5, 'dec_bias': torch.randn(12) * 0.1,
+         'enc_weight': torch.randn(8, 12) * 0.5, 'enc_bias': torch.randn(8) * 0.1}
+    K = 150
+    loader, per_batch, flat = [], [], []
+    for B in (12, 5):
+        P = K // B
+        x = (torch.rand(B, 12) < 0.4).float()
+        noises = [torch.randn(B, 4) for _ in range(B * P)]
+        loader.append((x, torch.zeros(B).long()))
+        per_batch.append(_draw_major(noises, B, P).to(DEV))
+        flat += noises
+    fast = make_model(g, E.ELBOMixin).eval()
+    fast.reparameterizer.train(True)
+    fast.config['vae_amd_likelihood_rows'] = rows
+    slow = make_model(g, Loop).eval()
+    slow.reparameterizer.train(True)
+    it = iter([n.to(DEV) for n in flat])
+    fwd = slow.reparameterizer.forward
+    slow.reparameterizer.forward = lambda lg, force=False, noise=None: fwd(lg, force=force, noise=next(it))
+    close(fast.likelihood(loader, K=K, noise=per_batch), slow.likelihood(loader, K=K), rtol=1e-5, atol=1e-5)
+    # Philox draws: reproducible, and close to the injected-noise estimate (same estimator, other draws)
+    import vae_amd
+    vae_amd.rng.manual_seed(9)
+    a = fast.likelihood(loader, K=K)
+    vae_amd.rng.manual_seed(9)
+    b = fast.likelihood(loader, K=K)
+    assert torch.equal(a, b) and bool(torch.isfinite(a))
 
 
 @pytest.mark.parametrize('B,L,S', [(1, 1, 1), (7, 3, 2), (64, 128, 4), (1000, 36, 3), (257, 512, 5)])

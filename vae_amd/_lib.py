@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the CDLL below, see module 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VAE_AMD_LIB') or os.path.join(_HERE, 'libvae_amd.so')  # env override: tuning builds only
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 VAE_OK, VAE_ERR_ARG, VAE_ERR_LAUNCH = 0, 1, 2
 VAE_F32, VAE_BF16, VAE_F16 = 0, 1, 2
@@ -66,7 +66,7 @@ SIGNATURES = {
                                     _p],
     'vae_nll_multi_elbo_fwd': [_p, _pp, _i64, _i, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
     'vae_nll_multi_elbo_bwd': [_p, _pp, _pp, _i64, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i64, _i64, _i, _p],
-    'vae_nll_steps_elbo_fwd': [_pp, _pp, _i64, _i, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
+    'vae_nll_steps_elbo_fwd': [_pp, _pp, _i64, _i, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
     'vae_nll_steps_elbo_bwd': [_pp, _pp, _pp, _i64, _i, _p, _p, _p, _p, _f, _f, _p, _i64, _i64, _i, _p],
     'vae_made_tail_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _i, _p],
     'vae_made_tail_bwd': [_p, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i, _i, _p],

@@ -6,7 +6,7 @@
 #include "../../include/vae_amd.h"
 
 extern "C" {
-int vae_abi_version(void) { return 8; }
+int vae_abi_version(void) { return 9; }
 // counters + group partials + one partial per block x up to 8 scalars (common.hpp, grid_reduce)
 size_t vae_workspace_bytes(void) { return vae::kWorkspaceFloats * sizeof(float); }
 

@@ -450,8 +450,8 @@ static bool fill_steps(Tab* tab, const void* const* xs, const void* const* recon
 
 template <typename T, int NLL>
 static int nll_steps_fwd_dispatch(const void* const* xs, const void* const* recons, int64_t steps, const void* kld,
-                                  void* nll, void* loss, void* elbo, void* loss_avg, void* elbo_avg, float* means,
-                                  float* workspace, int64_t B, int64_t D, float kl_beta, float inv_count,
+                                  void* nll, void* loss, void* elbo, void* loss_avg, void* elbo_avg, void* elbo_lse,
+                                  float* means, float* workspace, int64_t B, int64_t D, float kl_beta, float inv_count,
                                   hipStream_t stream) {
   constexpr int VN = VecOf<T>::n;
   StepRows<T, StepTable> src;
@@ -463,7 +463,7 @@ static int nll_steps_fwd_dispatch(const void* const* xs, const void* const* reco
   src.tps = (B + g.rows_per_block - 1) / g.rows_per_block;                // tiles never straddle steps
   nll_fwd_launch<T, NLL>(src, vec, g, src.tps * steps, kld, nullptr, nullptr, nll, loss, elbo, D, kl_beta, stream);
   launch_rows_means<T>(loss, elbo, nll, kld, nullptr, nullptr, workspace, inv_count, means, B * steps, stream, steps,
-                       loss_avg, elbo_avg);
+                       loss_avg, elbo_avg, elbo_lse);
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 
@@ -597,15 +597,16 @@ int vae_nll_elbo_bwd(const void* x, const void* recon, int nll_type, const void*
 
 int vae_nll_steps_elbo_fwd(const void* const* xs, const void* const* recons, int64_t steps, int nll_type,
                            const void* kld, float kl_beta, float inv_count, void* nll, void* loss, void* elbo,
-                           void* loss_avg, void* elbo_avg, float* means, float* workspace, int64_t B, int64_t D,
-                           int dtype, vae_stream_t stream) {
+                           void* loss_avg, void* elbo_avg, void* elbo_lse, float* means, float* workspace, int64_t B,
+                           int64_t D, int dtype, vae_stream_t stream) {
   if (B < 0 || D <= 0 || D > VAE_MAX_ROW || steps < 1 || steps > VAE_MAX_STEPS) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
-  if (!xs || !recons || !nll || !loss || !elbo || !loss_avg || !elbo_avg || !means || !workspace) return VAE_ERR_ARG;
+  if (!xs || !recons || !nll || !loss || !elbo || !means || !workspace) return VAE_ERR_ARG;
+  if ((loss_avg == nullptr) != (elbo_avg == nullptr)) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
 #define VAE_STEPS_FWD(TT, NN)                                                                                        \
-  return nll_steps_fwd_dispatch<TT, NN>(xs, recons, steps, kld, nll, loss, elbo, loss_avg, elbo_avg, means, workspace, \
-                                        B, D, kl_beta, inv_count, st)
+  return nll_steps_fwd_dispatch<TT, NN>(xs, recons, steps, kld, nll, loss, elbo, loss_avg, elbo_avg, elbo_lse, means, \
+                                        workspace, B, D, kl_beta, inv_count, st)
 #define VAE_STEPS_FWD_T(TT)                                       \
   switch (nll_type) {                                             \
     case VAE_NLL_BERNOULLI: VAE_STEPS_FWD(TT, VAE_NLL_BERNOULLI); \

@@ -167,7 +167,8 @@ __global__ __launch_bounds__(kBlock) void elbo_rows_means_kernel(const T* __rest
                                                                  const T* __restrict__ add, const T* __restrict__ mi,
                                                                  float* __restrict__ ws, float inv_count,
                                                                  float* __restrict__ means, int64_t B, int64_t steps,
-                                                                 T* __restrict__ loss_avg, T* __restrict__ elbo_avg) {
+                                                                 T* __restrict__ loss_avg, T* __restrict__ elbo_avg,
+                                                                 T* __restrict__ elbo_lse) {
   // per-sample averages over the steps of a [steps * Bs] launch (vrnn.py:767-803: the per-step [B] vectors are
   // summed one after the other in the tensor dtype, then divided by the step count)
   if (loss_avg) {
@@ -183,6 +184,19 @@ __global__ __launch_bounds__(kBlock) void elbo_rows_means_kernel(const T* __rest
       // with a CPU scalar divisor): the same here
       loss_avg[b] = from_f32<T>(mul_rn(sl, inv_steps));
       elbo_avg[b] = from_f32<T>(mul_rn(se, inv_steps));
+    }
+  }
+  // per-sample log-sum-exp over the steps of the elbo column: the importance-sampling estimate of
+  // abstract_vae.py:311-314 when the "steps" are draws of the same posterior (max first, as torch.logsumexp does)
+  if (elbo_lse) {
+    const int64_t Bs = B / steps;
+    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < Bs; b += (int64_t)gridDim.x * kBlock) {
+      float m = to_f32(elbo[b]);
+      for (int64_t t = 1; t < steps; ++t) m = fmaxf(m, to_f32(elbo[t * Bs + b]));
+      const float shift = (fabsf(m) == INFINITY) ? 0.0f : m;
+      float s = 0.0f;
+      for (int64_t t = 0; t < steps; ++t) s += expf(to_f32(elbo[t * Bs + b]) - shift);
+      elbo_lse[b] = from_f32<T>(logf(s) + shift);
     }
   }
   double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -220,7 +234,8 @@ __global__ __launch_bounds__(kBlock) void elbo_rows_means_kernel(const T* __rest
 template <typename T>
 inline void launch_rows_means(const void* loss, const void* elbo, const void* nll, const void* kld, const void* add,
                               const void* mi, float* ws, float inv_count, float* means, int64_t B, hipStream_t stream,
-                              int64_t steps = 1, void* loss_avg = nullptr, void* elbo_avg = nullptr) {
+                              int64_t steps = 1, void* loss_avg = nullptr, void* elbo_avg = nullptr,
+                              void* elbo_lse = nullptr) {
   constexpr int VN = VecOf<T>::n;
   const bool vec = aligned16(loss) && aligned16(elbo) && aligned16(nll) && (!kld || aligned16(kld)) &&
                    (!add || aligned16(add)) && (!mi || aligned16(mi));
@@ -230,11 +245,11 @@ inline void launch_rows_means(const void* loss, const void* elbo, const void* nl
   if (vec)
     hipLaunchKernelGGL((elbo_rows_means_kernel<T, VN>), dim3(grid), dim3(kBlock), 0, stream, (const T*)loss, (const T*)elbo,
                        (const T*)nll, (const T*)kld, (const T*)add, (const T*)mi, ws, inv_count, means, B, steps,
-                       (T*)loss_avg, (T*)elbo_avg);
+                       (T*)loss_avg, (T*)elbo_avg, (T*)elbo_lse);
   else
     hipLaunchKernelGGL((elbo_rows_means_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, stream, (const T*)loss, (const T*)elbo,
                        (const T*)nll, (const T*)kld, (const T*)add, (const T*)mi, ws, inv_count, means, B, steps,
-                       (T*)loss_avg, (T*)elbo_avg);
+                       (T*)loss_avg, (T*)elbo_avg, (T*)elbo_lse);
 }
 
 }  // namespace vae

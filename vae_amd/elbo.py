@@ -10,6 +10,7 @@ that hold tensors only.
 import torch
 
 from . import functional as F_
+from . import rng
 
 MEAN_KEYS = ('loss_mean', 'elbo_mean', 'nll_mean', 'kld_mean', 'additional_loss_mean', 'mut_info_mean')
 
@@ -168,11 +169,25 @@ class ELBOMixin(object):
         self.nan_check()
         return out
 
-    def likelihood(self, loader, K=1000):
-        """abstract_vae.py:281-317, quirks included: every sample is expanded to a batch of itself, drawn
-        K // B times through reparameterize() (which returns the MEAN for a Gaussian in eval mode), and the
-        log-sum-exp of the (K // B) * B elbo values is lowered by log(K // B), not by log of their number."""
+    def likelihood(self, loader, K=1000, noise=None):
+        """abstract_vae.py:281-317: per sample, the log-sum-exp of the elbo over (K // B) * B draws of its posterior,
+        lowered by log(K // B) (the reference's normalisation, not the log of the number of values: kept), averaged
+        over every sample the loader yields.
+
+        With the model in eval mode, the stock reparameterize() / kld() and an IsotropicGaussian, a minibatch costs
+        a handful of launches instead of B * (K // B) Python iterations of ~40 launches on expand().contiguous()
+        copies: all draws of a group of samples come from ONE read of their logits (csrc/multi.hip, z [S, n, L]), go
+        through ONE decoder call, and are scored by the step-table NLL + ELBO launch (csrc/elbo.hip: up to 128 draws
+        per launch read the targets where they are) whose closing launch folds the log-sum-exp over the draws.
+        config['vae_amd_likelihood_rows'] (default 65536) bounds the decoder batch.  `noise`: optional iterable of
+        one [S, B, L] tensor per minibatch (S = (K // B) * B, draw-major) in place of the in-kernel Philox draws.
+        Anything else -- a model in training mode (batch-norm decoders see other batches), an overridden
+        reparameterize / kld, another reparameterizer -- takes the reference's loop."""
         import math
+        from .reparameterizers.isotropic_gaussian import IsotropicGaussian
+        batched = (not self.training and type(self).reparameterize is ELBOMixin.reparameterize
+                   and type(self).kld is ELBOMixin.kld and type(self.reparameterizer) is IsotropicGaussian)
+        noise = iter(noise) if noise is not None else None
         with torch.no_grad():
             likelihood = []
             for minibatch, labels in loader:
@@ -181,18 +196,58 @@ class ELBOMixin(object):
                 labels = labels.to(dev) if dev else minibatch
                 z_logits = self.encode(minibatch)
                 batch_size = z_logits.shape[0]
+                passes = K // batch_size
+                if batched and z_logits.dim() == 2 and passes >= 1:
+                    lse = self._likelihood_minibatch(minibatch, z_logits, passes,
+                                                     None if noise is None else next(noise))
+                    likelihood.append(lse - math.log(passes))
+                    continue
                 for idx in range(batch_size):
                     z_logits_i = z_logits[idx].expand_as(z_logits).contiguous()
                     sample_i = minibatch[idx].expand_as(minibatch).contiguous()
                     label_i = labels[idx].expand_as(labels).contiguous()
                     elbo = []
-                    for count in range(K // batch_size):
+                    for count in range(passes):
                         z, params = self.reparameterize(z_logits_i, labels=label_i)
                         loss_t = self.loss_function(self.decode(z), sample_i, params=params)
                         elbo.append(loss_t['elbo'])
                     flat = torch.cat([e.unsqueeze(0) for e in elbo], 0).view([-1])
-                    likelihood.append(torch.logsumexp(flat, dim=0) - math.log(count + 1))
-            return torch.mean(torch.cat([l.unsqueeze(0) for l in likelihood], 0))
+                    likelihood.append((torch.logsumexp(flat, dim=0) - math.log(count + 1)).reshape(1))
+            return torch.mean(torch.cat(likelihood, 0))
+
+    def _likelihood_minibatch(self, x, z_logits, passes, noise=None):
+        """[B] log-sum-exp over S = passes * B draws per sample of elbo = nll + kld (abstract_vae.py:301-315, :357)."""
+        import math
+        rep = self.reparameterizer
+        B, L = z_logits.shape[0], rep.output_size
+        S = passes * B
+        if not rep.training:
+            # eval-mode reparameterizer: every "draw" is the posterior mean (isotropic_gaussian.py:100-112), the S
+            # values are one value: decode it once
+            z, params = self.reparameterize(z_logits)
+            return self.loss_function(self.decode(z), x, params=params)['elbo'] + math.log(S)
+        rows = max(int(self.config.get('vae_amd_likelihood_rows', 1 << 16)), 1)
+        group = max(min(rows // S, B), 1)                      # samples per decoder call
+        draws = min(S, rows) if group == 1 else S              # draws per decoder call (a lone sample may need several)
+        out = []
+        for i0 in range(0, B, group):
+            lg, xi = z_logits[i0:i0 + group], x[i0:i0 + group]
+            n = lg.shape[0]
+            parts = []
+            for s0 in range(0, S, draws):
+                Sc = min(draws, S - s0)
+                nz = None if noise is None else noise[s0:s0 + Sc, i0:i0 + n]
+                seed, offset = (0, 0) if nz is not None else rng.next_calls(Sc)
+                z, _, kld, _ = F_.gauss_reparam_multi(lg, Sc, noise=nz, eps_tol=rep.eps_tol, seed=seed, offset=offset,
+                                                      row0=rep.row_offset + i0, want_logvar=False)
+                recon = self.decode(z.view(Sc * n, L))
+                recon = recon.view((Sc, n) + tuple(recon.shape[1:]))
+                for t0 in range(0, Sc, F_.MAX_STEPS):
+                    T = min(F_.MAX_STEPS, Sc - t0)
+                    parts.append(F_.nll_steps_elbo([xi] * T, [recon[t] for t in range(t0, t0 + T)],
+                                                   self.config['nll_type'], kld=kld.repeat(T), with_lse=True)[6])
+            out.append(parts[0] if len(parts) == 1 else torch.logsumexp(torch.stack(parts, 0), 0))
+        return torch.cat(out, 0)
 
 
 class MSGMixin(ELBOMixin):

@@ -1028,7 +1028,7 @@ class _NllStepsElbo(torch.autograd.Function):
     """T per-step (target, reconstruction) pairs scored as one [T*B] launch, the tensors read where they are."""
 
     @staticmethod
-    def forward(ctx, kld, nll_code, kl_beta, inv_count, T, *tensors):
+    def forward(ctx, kld, nll_code, kl_beta, inv_count, T, with_lse, *tensors):
         ctx.set_materialize_grads(False)
         xs, recons = tensors[:T], tensors[T:]
         dev = check_device(kld, *tensors)
@@ -1036,17 +1036,21 @@ class _NllStepsElbo(torch.autograd.Function):
         dt = recons[0].dtype
         new = lambda n: torch.empty((n,), dtype=dt, device=dev)
         nll, loss, elbo, loss_avg, elbo_avg = new(T * B), new(T * B), new(T * B), new(B), new(B)
+        lse = new(B) if with_lse else None
         means = _scalars(6, dev, B)
         with _Guard(dev):
             call('vae_nll_steps_elbo_fwd', _lib.ptr_array(xs), _lib.ptr_array(recons), T, nll_code, ptr(kld), kl_beta,
-                 inv_count, ptr(nll), ptr(loss), ptr(elbo), ptr(loss_avg), ptr(elbo_avg), ptr(means),
+                 inv_count, ptr(nll), ptr(loss), ptr(elbo), ptr(loss_avg), ptr(elbo_avg), ptr(lse), ptr(means),
                  ptr(workspace(dev)), B, D, dtype_code(recons[0]), stream_ptr(dev))
         ctx.save_for_backward(*tensors)
         ctx.cfg = (nll_code, kl_beta, inv_count, T, kld is not None)
-        return nll, loss, elbo, means, loss_avg, elbo_avg
+        if lse is None:
+            lse = new(0)
+        ctx.mark_non_differentiable(lse)
+        return nll, loss, elbo, means, loss_avg, elbo_avg, lse
 
     @staticmethod
-    def backward(ctx, gnll, gloss, gelbo, gmeans, gloss_avg, gelbo_avg):
+    def backward(ctx, gnll, gloss, gelbo, gmeans, gloss_avg, gelbo_avg, glse):
         nll_code, kl_beta, inv_count, T, has_kld = ctx.cfg
         xs, recons = ctx.saved_tensors[:T], ctx.saved_tensors[T:]
         dev = xs[0].device
@@ -1066,14 +1070,16 @@ class _NllStepsElbo(torch.autograd.Function):
             call('vae_nll_steps_elbo_bwd', _lib.ptr_array(xs), _lib.ptr_array(recons), _lib.ptr_array(grecons), T,
                  nll_code, ptr(gnll), ptr(gloss), ptr(gelbo), ptr(gmeans), kl_beta, inv_count, ptr(gkld), B, D,
                  dtype_code(recons[0]), stream_ptr(dev))
-        return (gkld, None, None, None, None) + (None,) * T + tuple(grecons)
+        return (gkld, None, None, None, None, None) + (None,) * T + tuple(grecons)
 
 
-def nll_steps_elbo(xs, recons, nll_type, kld=None, kl_beta=1.0, inv_count=None):
+def nll_steps_elbo(xs, recons, nll_type, kld=None, kl_beta=1.0, inv_count=None, with_lse=False):
     """The VRNN loss (vrnn.py:805-829) over T = len(recons) time steps in one launch pair: xs / recons are the per-step
     targets and decoder outputs (a tensor may repeat), kld the per-step KL vectors concatenated [T*B].
     Returns (nll, loss, elbo [T*B], means float32[6], loss_avg, elbo_avg [B]); the means are over all T*B entries
-    (= the mean over steps of the per-step means), the averages are per sample over the steps."""
+    (= the mean over steps of the per-step means), the averages are per sample over the steps.
+    with_lse=True appends logsumexp over the steps of elbo, [B] (not differentiable): the steps are then draws of one
+    posterior per sample, AbstractVAE.likelihood's estimate (abstract_vae.py:301-315)."""
     T = len(recons)
     assert 1 <= T <= MAX_STEPS and len(xs) == T
     flat = [_flat_pixels(x, r, nll_type) for x, r in zip(xs, recons)]
@@ -1085,7 +1091,8 @@ def nll_steps_elbo(xs, recons, nll_type, kld=None, kl_beta=1.0, inv_count=None):
             raise ValueError("nll_steps_elbo: every step must have the same shapes and dtype")
     if inv_count is None:
         inv_count = 1.0 / max(T * B, 1)
-    return _NllStepsElbo.apply(_dense(kld), code, float(kl_beta), float(inv_count), T, *xf, *rf)
+    out = _NllStepsElbo.apply(_dense(kld), code, float(kl_beta), float(inv_count), T, bool(with_lse), *xf, *rf)
+    return out if with_lse else out[:6]
 
 
 # --------------------------------------------------------------------------------------
