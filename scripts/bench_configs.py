@@ -48,7 +48,7 @@ def timeit(name, cfg, fn, nbytes, iters=20):
         if _flush is None:
             _flush = torch.empty(512 << 18, device=dev)      # 512 MiB of fp32
         samples = []
-        for _ in range(9):
+        for _ in range(int(os.environ.get('BENCH_COLD_SAMPLES', '9'))):
             _flush.fill_(1.0)
             e0.record()
             fn()

@@ -237,6 +237,27 @@ __global__ __launch_bounds__(kBlock) void gauss_kl_bwd_kernel(
   }
 }
 
+// Launch geometry of the two Gaussian kernels on top of row_geom's general rule, from the r02 cold-cache sweep
+// (scripts/sweep_geom.py; profiles/r02_geom_sweep.txt): rows of 65..128 vectors run two rows per wave in the forward
+// (G = 32, two chunks in flight: fp32 L = 512 96.6 -> 94.1 us, bf16 L = 1024 101.9 -> 95.5 us), and a kernel that
+// draws its noise from Philox keeps ONE chunk in flight (the generator's registers cost occupancy: fp32 L = 512
+// forward 79.0 -> 72.6 us, backward 111.2 -> 106.1 us; rows above 128 vectors keep four chunks in the backward).
+static RowGeom gauss_geom(int64_t B, int64_t vecs, int64_t max_grid, bool philox, bool fwd) {
+  RowGeom g = row_geom(B, vecs, max_grid);
+  if (knobs().G || knobs().U) return g;
+  if (fwd && vecs > 64 && vecs <= 128) {
+    if (g.grid < g.tiles) max_grid = g.grid;   // a cap row_geom took from the tuning knobs
+    g.G = 32;
+    g.U = 2;
+    g.rows_per_block = kBlock / g.G;
+    g.tiles = (B + g.rows_per_block - 1) / g.rows_per_block;
+    g.grid = (int)(g.tiles < max_grid ? g.tiles : max_grid);
+    if (g.grid < 1) g.grid = 1;
+  }
+  if (philox && (fwd || vecs <= 128)) g.U = 1;
+  return g;
+}
+
 template <typename T>
 static int gauss_fwd_dispatch(const void* logits, int64_t row_stride, const void* noise, void* z, int64_t z_stride,
                               void* s_out,
@@ -247,7 +268,7 @@ static int gauss_fwd_dispatch(const void* logits, int64_t row_stride, const void
   const bool vec = (L % VN == 0) && (row_stride % VN == 0) && (z_stride % VN == 0) && aligned16(logits) &&
                    (!z || aligned16(z)) &&
                    (!noise || aligned16(noise)) && (!s_out || aligned16(s_out));
-  const RowGeom g = row_geom(B, vec ? L / VN : L, means ? kGridReduce : kGridStream);
+  const RowGeom g = gauss_geom(B, vec ? L / VN : L, means ? kGridReduce : kGridStream, training && !noise, true);
   if (!means) workspace = nullptr;
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gauss_fwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
@@ -273,7 +294,7 @@ static int gauss_bwd_dispatch(const void* logits, int64_t row_stride, const void
   const bool vec = (L % VN == 0) && (row_stride % VN == 0) && (gz_stride % VN == 0) && (gl_stride % VN == 0) &&
                    aligned16(logits) && aligned16(glogits) &&
                    (!noise || aligned16(noise)) && (!gz || aligned16(gz)) && (!gs || aligned16(gs));
-  const RowGeom g = row_geom(B, vec ? L / VN : L, kGridStream);
+  const RowGeom g = gauss_geom(B, vec ? L / VN : L, kGridStream, training && !noise, false);
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gauss_bwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
                                          (const T*)logits, row_stride, (const T*)noise, (const T*)gz, gz_stride,
