@@ -43,12 +43,14 @@ enum { VAE_F32 = 0, VAE_BF16 = 1, VAE_F16 = 2 };
 enum { VAE_NLL_BERNOULLI = 0, VAE_NLL_GAUSSIAN = 1, VAE_NLL_DISC_LOGISTIC = 2 };
 
 #define VAE_MAX_ROW (1 << 24) /* longest supported row (elements) */
-/* softmax-class kernels keep the row in registers: 4 x 256 16-byte vectors (fp32; bf16 rows
- * may be twice as long when K % 8 == 0); unaligned rows (K % 4 != 0) are limited to 1024.   */
+/* softmax-class kernels keep the row in registers up to 4 x 256 16-byte vectors (K <= 4096 fp32, twice that in
+ * the 16-bit types when K % 8 == 0; 1024 for unaligned rows, K % 4 != 0): one read of every input.  Longer rows
+ * (up to VAE_MAX_ROW) run one block per row and stream the row three times (maxima, sums, outputs).          */
 #define VAE_MAX_SOFTMAX_ROW 4096
 #define VAE_MAX_SAMPLES 8   /* decoder outputs one vae_nll_multi_elbo_* call combines */
 #define VAE_MAX_STEPS 128   /* time steps one vae_nll_steps_elbo_* call scores (pointer tables in the kernel arguments) */
-#define VAE_MAX_BN_ROW 4096 /* widest BatchNormFlow layer (F % 4 == 0 fp32 / F % 8 == 0 bf16; 1024 otherwise) */
+#define VAE_MAX_BN_ROW 4096 /* BatchNormFlow layers up to this width (1024 unaligned) take their column moments in one
+                             * launch; wider ones (any F <= VAE_MAX_ROW) one launch per window of that many columns */
 
 /* ABI version of this header; bumped on any signature change. */
 int vae_abi_version(void);
@@ -142,7 +144,7 @@ int vae_gauss_pair_bwd(const void* enc_logits, int64_t stride_enc, const void* p
  *   logits [B, K] rows `row_stride` apart; unif [B, K] uniform draws or NULL
  *   (Philox keyed by (seed, offset, row0 + row, col)); y, z_hard, log_q_z [B, K], each may be
  *   NULL (not written; at least one is given; log_q_z alone skips the draw and the softmax).
- *   K <= VAE_MAX_SOFTMAX_ROW.                                                     */
+ *   Any K <= VAE_MAX_ROW (K > VAE_MAX_SOFTMAX_ROW: the streamed three-pass kernels).   */
 int vae_gumbel_fwd(const void* logits, int64_t row_stride, const void* unif, void* y, int64_t y_stride, void* z_hard,
                    int64_t z_hard_stride, void* log_q_z,
                    int64_t B, int64_t K, float tau, uint64_t seed, uint64_t offset, int64_t row0, int dtype,
@@ -366,7 +368,7 @@ int vae_coupling_tail_bwd(const void* x, const void* s_raw, const float* mask, c
  *   (backward) [6F,7F) sum_b gy = d beta | [7F,8F) sum_b gy*x_hat | [8F] sum_b glogdet | two [F] vectors of
  *   backward constants | block partials.
  *   The caller updates the running statistics from stats[0,2F) (:240-246) and forms
- *   d log_gamma = exp(log_gamma) * stats[7F..8F) + stats[8F].  F <= VAE_MAX_BN_ROW.               */
+ *   d log_gamma = exp(log_gamma) * stats[7F..8F) + stats[8F].  F <= VAE_MAX_ROW.                  */
 size_t vae_bnflow_stats_floats(int64_t F);
 int vae_bnflow_fwd(const void* x, const float* log_gamma, const float* beta, const float* mean_in, const float* var_in,
                    float* stats, void* y, const void* logdet_in, void* logdet_out, int64_t B, int64_t F, float eps,

@@ -187,7 +187,7 @@ def test_coupling_tail_vs_oracle(B, Fd, additive):
 
 
 @pytest.mark.parametrize('B,Fd', [(2, 1), (8, 6), (100, 64), (1000, 100), (4096, 512), (777, 1024), (300, 1022),
-                                  (513, 2048), (260, 4096)])
+                                  (513, 2048), (260, 4096), (70, 4100), (33, 9000), (5, 1030), (12, 16384 + 8)])
 @pytest.mark.parametrize('train', [True, False])
 @pytest.mark.parametrize('reverse', [False, True])
 def test_bnflow_vs_oracle(B, Fd, train, reverse):
@@ -258,8 +258,8 @@ def test_flowtail_empty_and_limits():
     from vae_amd import functional as F_
     u, ld = F_.made_tail(torch.zeros(0, 8, device=DEV), torch.zeros(0, 16, device=DEV))
     assert u.shape == (0, 8) and ld.shape == (0,)
-    with pytest.raises(RuntimeError):   # wider than VAE_MAX_BN_ROW
-        F_.bnflow(torch.zeros(4, 8192, device=DEV), torch.zeros(8192, device=DEV), torch.zeros(8192, device=DEV))
+    with pytest.raises(ValueError):   # parameter vectors of the wrong width
+        F_.bnflow(torch.zeros(4, 64, device=DEV), torch.zeros(32, device=DEV), torch.zeros(64, device=DEV))
 
 
 def test_flow_reparameterizer_with_kernel_backed_maf():

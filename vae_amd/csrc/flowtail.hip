@@ -254,7 +254,9 @@ template <typename T, int V, int NJ, int R>
 __global__ __launch_bounds__(kBlock) void bn_colstats_kernel(
     const T* __restrict__ x, const T* __restrict__ gy, const T* __restrict__ gld, const float* __restrict__ mean,
     const float* __restrict__ rstd, float* __restrict__ part, int64_t B, int F, int mode, int rev, int G,
-    int64_t tiles) {
+    int64_t tiles, int jbase, int wvec) {
+  // columns: the window of `wvec` vectors that starts at vector `jbase` (the whole row when it fits kBnChunks
+  // vectors per lane; rows wider than that take one launch per window of 4 * kBlock vectors)
   __shared__ float lds[NJ * V * kBlock];   // [slot][tid], slot < NJ*V; one statistic at a time
   const int rpb = kBlock / G;
   const int sub = threadIdx.x % G;
@@ -267,8 +269,8 @@ __global__ __launch_bounds__(kBlock) void bn_colstats_kernel(
 #pragma unroll
   for (int k = 0; k < NJ; ++k) {
     const int j = sub + k * G;
-    jv[k] = j < nvec;
-    jc[k] = jv[k] ? j : nvec - 1;
+    jv[k] = j < wvec;
+    jc[k] = jbase + (jv[k] ? j : wvec - 1);
 #pragma unroll
     for (int i = 0; i < V; ++i) { a1[k][i] = 0.f; a2[k][i] = 0.f; c1[k][i] = 1.f; }
     if (mode == 0) {
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void bn_colstats_kernel(
         load_vec<T, V>(x + rowc * F + (int64_t)jc[k] * V, xv[r][k]);
         if (mode == 1) load_vec_rev<T, V>(gy + rowc * F, jc[k], nvec, rev != 0, gv[r][k]);
       }
-      if (mode == 1 && gld && sub == 0 && rv[r]) extra += to_f32(gld[row]);
+      if (mode == 1 && gld && sub == 0 && jbase == 0 && rv[r]) extra += to_f32(gld[row]);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -327,10 +329,10 @@ __global__ __launch_bounds__(kBlock) void bn_colstats_kernel(
       for (int q = rloc; q < NJ * V; q += rpb) {
         const int k = q / V, i = q % V;
         const int j = sub + k * G;
-        if (j < nvec) {
+        if (j < wvec) {
           float s = 0.f;
           for (int r = 0; r < rpb; ++r) s += lds[q * kBlock + r * G + sub];
-          mypart[(size_t)st * F + (size_t)j * V + i] = s;
+          mypart[(size_t)st * F + (size_t)(jbase + j) * V + i] = s;
         }
       }
     }
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(kBlock) void bn_colstats_kernel(
   float e = wave_sum(extra);
   if ((threadIdx.x & 63) == 0) ex[threadIdx.x >> 6] = e;
   __syncthreads();
-  if (threadIdx.x == 0) mypart[2 * (size_t)F] = ex[0] + ex[1] + ex[2] + ex[3];
+  if (threadIdx.x == 0 && jbase == 0) mypart[2 * (size_t)F] = ex[0] + ex[1] + ex[2] + ex[3];
 }
 
 // Second step: 8 columns x 32 partial-groups per block; block order, double.
@@ -561,33 +563,36 @@ __global__ __launch_bounds__(kBlock) void bn_apply_bwd_kernel(
 
 // geometry for the column-moment kernel: >= 2 vectors per lane up to a whole wave per row, then wider groups
 // until the row fits kBnChunks vectors per lane
-static bool bn_geom(int64_t B, int64_t nvec, int* G_out, int* NJ_out, int64_t* tiles, int* grid) {
+static void bn_geom(int64_t B, int64_t nvec, int* G_out, int* NJ_out, int64_t* tiles, int* grid) {
   int G = 1;
   while (G < 64 && (int64_t)G * 2 < nvec) G <<= 1;
   while (G < kBlock && (int64_t)G * kBnChunks < nvec) G <<= 1;
-  if ((int64_t)G * kBnChunks < nvec) return false;
-  const int64_t per = (nvec + G - 1) / G;
+  // wider than kBlock * kBnChunks vectors: the block owns a row and the launch is repeated per column window
+  const int64_t per = (int64_t)G * kBnChunks < nvec ? kBnChunks : (nvec + G - 1) / G;
   *NJ_out = per >= 3 ? 4 : (per == 2 ? 2 : 1);
   const int rpb = kBlock / G;
   *G_out = G;
   *tiles = (B + rpb - 1) / rpb;
   *grid = (int)(*tiles < kBnGrid ? *tiles : kBnGrid);
-  return true;
 }
 
 template <typename T, int V>
 static void bn_colstats_launch(int NJ, int grid, hipStream_t st, const T* x, const T* gy, const T* gld, const float* mean,
                                const float* rstd, float* part, int64_t B, int F, int mode, int rev, int G,
                                int64_t tiles) {
+  const int nvec = F / V;
   if (NJ == 1)
     hipLaunchKernelGGL((bn_colstats_kernel<T, V, 1, 4>), dim3(grid), dim3(kBlock), 0, st, x, gy, gld, mean, rstd, part,
-                       B, F, mode, rev, G, tiles);
+                       B, F, mode, rev, G, tiles, 0, nvec);
   else if (NJ == 2)
     hipLaunchKernelGGL((bn_colstats_kernel<T, V, 2, 4>), dim3(grid), dim3(kBlock), 0, st, x, gy, gld, mean, rstd, part,
-                       B, F, mode, rev, G, tiles);
+                       B, F, mode, rev, G, tiles, 0, nvec);
   else
-    hipLaunchKernelGGL((bn_colstats_kernel<T, V, 4, 2>), dim3(grid), dim3(kBlock), 0, st, x, gy, gld, mean, rstd, part,
-                       B, F, mode, rev, G, tiles);
+    for (int j0 = 0; j0 < nvec; j0 += G * kBnChunks) {   // one window unless the row is wider than kBlock * kBnChunks vectors
+      const int w = nvec - j0 < G * kBnChunks ? nvec - j0 : G * kBnChunks;
+      hipLaunchKernelGGL((bn_colstats_kernel<T, V, 4, 2>), dim3(grid), dim3(kBlock), 0, st, x, gy, gld, mean, rstd, part,
+                         B, F, mode, rev, G, tiles, j0, w);
+    }
 }
 
 template <typename T>
@@ -685,7 +690,7 @@ static int bn_fwd_dispatch(const void* x, const float* lg, const float* beta, co
   if (training) {
     int G, NJ, grid;
     int64_t tiles;
-    if (!bn_geom(B, vec ? F / VN : F, &G, &NJ, &tiles, &grid)) return VAE_ERR_ARG;
+    bn_geom(B, vec ? F / VN : F, &G, &NJ, &tiles, &grid);
     if (vec)
       bn_colstats_launch<T, VN>(NJ, grid, st, (const T*)x, nullptr, nullptr, nullptr, nullptr, part, B, (int)F, 0, 0, G,
                                 tiles);
@@ -724,7 +729,7 @@ static int bn_bwd_dispatch(const void* x, const void* gy, const void* gld, float
   if (phase != 2) {
     int G, NJ, grid;
     int64_t tiles;
-    if (!bn_geom(B, vec ? F / VN : F, &G, &NJ, &tiles, &grid)) return VAE_ERR_ARG;
+    bn_geom(B, vec ? F / VN : F, &G, &NJ, &tiles, &grid);
     if (vec)
       bn_colstats_launch<T, VN>(NJ, grid, st, (const T*)x, (const T*)gy, (const T*)gld, mean, rstd, part, B, (int)F, 1,
                                 rev, G, tiles);
@@ -822,7 +827,7 @@ size_t vae_bnflow_stats_floats(int64_t F) { return F > 0 ? bn_stats_floats(F) : 
 int vae_bnflow_fwd(const void* x, const float* log_gamma, const float* beta, const float* mean_in, const float* var_in,
                    float* stats, void* y, const void* logdet_in, void* logdet_out, int64_t B, int64_t F, float eps,
                    int training, int reverse, int dtype, vae_stream_t stream) {
-  if (B < 0 || F <= 0 || F > VAE_MAX_BN_ROW) return VAE_ERR_ARG;
+  if (B < 0 || F <= 0 || F > VAE_MAX_ROW) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
   if (!x || !log_gamma || !beta || !stats) return VAE_ERR_ARG;
   if ((!y || !logdet_out) && !(training && !y)) return VAE_ERR_ARG;  // y == NULL: training statistics only
@@ -842,7 +847,7 @@ int vae_bnflow_fwd(const void* x, const float* log_gamma, const float* beta, con
 
 int vae_bnflow_bwd(const void* x, const void* gy, const void* glogdet, float* stats, void* gx, int64_t B, int64_t F,
                    int training, int reverse, int dtype, vae_stream_t stream) {
-  if (B < 0 || F <= 0 || F > VAE_MAX_BN_ROW) return VAE_ERR_ARG;
+  if (B < 0 || F <= 0 || F > VAE_MAX_ROW) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
   if (!x || !gy || !stats || !gx) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -854,7 +859,7 @@ int vae_bnflow_bwd(const void* x, const void* gy, const void* glogdet, float* st
 
 int vae_bnflow_bwd_sums(const void* x, const void* gy, const void* glogdet, float* stats, int64_t B, int64_t F,
                         int reverse, int dtype, vae_stream_t stream) {
-  if (B < 0 || F <= 0 || F > VAE_MAX_BN_ROW) return VAE_ERR_ARG;
+  if (B < 0 || F <= 0 || F > VAE_MAX_ROW) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
   if (!x || !gy || !stats) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -866,7 +871,7 @@ int vae_bnflow_bwd_sums(const void* x, const void* gy, const void* glogdet, floa
 
 int vae_bnflow_bwd_apply(const void* x, const void* gy, float* stats, void* gx, int64_t B, int64_t F, int64_t count,
                          int reverse, int dtype, vae_stream_t stream) {
-  if (B < 0 || F <= 0 || F > VAE_MAX_BN_ROW || count < B || count <= 0) return VAE_ERR_ARG;
+  if (B < 0 || F <= 0 || F > VAE_MAX_ROW || count < B || count <= 0) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
   if (!x || !gy || !stats || !gx) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;

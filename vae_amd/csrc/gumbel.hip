@@ -310,6 +310,224 @@ __global__ __launch_bounds__(kBlock) void categorical_kl_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Rows too long for the register-resident kernels above (more than 4 * 256 vectors: K > 4096 fp32, 8192 in the
+// 16-bit types; the reference has no limit, gumbel.py:110-124): one block per row, the row streamed three times
+// (maxima, sums, outputs).  A row is at most 64 MiB and normally a few hundred KiB, so the second and third pass
+// come out of L2 / Infinity Cache; the arithmetic is the resident kernels', element for element.
+// ---------------------------------------------------------------------------
+template <typename T, int V>
+__device__ __forceinline__ void gumbel_logit(const float (&l)[V], float (&u)[V], bool injected, float tau,
+                                             float (&x)[V]) {
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    float g;
+    if (injected) {
+      g = -logf(add_rn(u[i], kGumbelEps));
+      g = -logf(add_rn(g, kGumbelEps));
+    } else {
+      g = -fast_log(u[i] + kGumbelEps);
+      g = -fast_log(g + kGumbelEps);
+    }
+    g = to_f32(from_f32<T>(g));
+    const float xi = to_f32(from_f32<T>(div_rn(to_f32(from_f32<T>(add_rn(l[i], g))), tau)));
+    x[i] = to_f32(from_f32<T>(add_rn(xi, kGumbelEps)));
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(kBlock) void gumbel_fwd_long_kernel(
+    const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ unif, T* __restrict__ y_out,
+    int64_t y_stride, T* __restrict__ zh_out, int64_t zh_stride, T* __restrict__ lq_out, int64_t B, int K, float tau,
+    uint64_t seed, uint64_t offset, int64_t row0) {
+  const int nvec = K / V;
+  const bool want_lq = lq_out != nullptr;
+  const bool want_soft = y_out != nullptr || zh_out != nullptr;
+  for (int64_t row = blockIdx.x; row < B; row += gridDim.x) {
+    const T* lr = logits + row * row_stride;
+    const T* ur = unif ? unif + row * (int64_t)K : nullptr;
+    auto logit_x = [&](int j, const float (&l)[V], float (&x)[V]) {
+      float u[V];
+      if (ur) load_vec<T, V>(ur + (int64_t)j * V, u);
+      else philox_uniform<V>(seed, offset, (uint64_t)(row0 + row) * (uint64_t)K + (uint64_t)j * V, u);
+      gumbel_logit<T, V>(l, u, ur != nullptr, tau, x);
+    };
+    float m1 = kNegInf, m2 = kNegInf;
+    for (int j = threadIdx.x; j < nvec; j += kBlock) {
+      float l[V], x[V];
+      load_vec<T, V>(lr + (int64_t)j * V, l);
+#pragma unroll
+      for (int i = 0; i < V; ++i) m1 = fmaxf(m1, l[i]);
+      if (want_soft) {
+        logit_x(j, l, x);
+#pragma unroll
+        for (int i = 0; i < V; ++i) m2 = fmaxf(m2, x[i]);
+      }
+    }
+    m1 = row_max(m1, kBlock);
+    if (want_soft) m2 = row_max(m2, kBlock);
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = threadIdx.x; j < nvec; j += kBlock) {
+      float l[V], x[V];
+      load_vec<T, V>(lr + (int64_t)j * V, l);
+      if (want_lq)
+#pragma unroll
+        for (int i = 0; i < V; ++i) s1 += exp_acc(sub_rn(l[i], m1));
+      if (want_soft) {
+        logit_x(j, l, x);
+#pragma unroll
+        for (int i = 0; i < V; ++i) s2 += expf(sub_rn(x[i], m2));
+      }
+    }
+    float lse = 0.f, rinv = 0.f, ymax = 0.f;
+    if (want_lq) lse = logf(row_sum(s1, kBlock));
+    if (want_soft) {
+      rinv = div_rn(1.0f, row_sum(s2, kBlock));
+      ymax = to_f32(from_f32<T>(rinv));   // the largest y is the one at x = max: exp(0) * rinv, rounded as every y is
+    }
+    for (int j = threadIdx.x; j < nvec; j += kBlock) {
+      float l[V], x[V], zh[V], lq[V];
+      load_vec<T, V>(lr + (int64_t)j * V, l);
+      if (want_soft) {
+        logit_x(j, l, x);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          x[i] = to_f32(from_f32<T>(mul_rn(expf(sub_rn(x[i], m2)), rinv)));
+          const float h = (x[i] == ymax) ? 1.0f : 0.0f;
+          zh[i] = add_rn(to_f32(from_f32<T>(sub_rn(h, x[i]))), x[i]);
+        }
+        if (y_out) store_vec<T, V>(y_out + row * y_stride + (int64_t)j * V, x);
+        if (zh_out) store_vec<T, V>(zh_out + row * zh_stride + (int64_t)j * V, zh);
+      }
+      if (want_lq) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) lq[i] = sub_rn(sub_rn(l[i], m1), lse);
+        store_vec<T, V>(lq_out + row * (int64_t)K + (int64_t)j * V, lq);
+      }
+    }
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(kBlock) void gumbel_bwd_long_kernel(
+    const T* __restrict__ y, int64_t y_stride, const T* __restrict__ lq, const T* __restrict__ gy, int64_t gy_stride,
+    const T* __restrict__ gzh, int64_t gzh_stride, const T* __restrict__ glq, T* __restrict__ glogits,
+    int64_t gl_stride, int64_t B, int K, float tau) {
+  const int nvec = K / V;
+  const float itau = 1.0f / tau;
+  const bool soft = gy || gzh;
+  for (int64_t row = blockIdx.x; row < B; row += gridDim.x) {
+    auto upstream = [&](int j, float (&gt)[V]) {   // gy + gzh: the straight-through sample passes its gradient to y
+      float q[V];
+#pragma unroll
+      for (int i = 0; i < V; ++i) gt[i] = 0.f;
+      if (gy) load_vec<T, V>(gy + row * gy_stride + (int64_t)j * V, gt);
+      if (gzh) {
+        load_vec<T, V>(gzh + row * gzh_stride + (int64_t)j * V, q);
+#pragma unroll
+        for (int i = 0; i < V; ++i) gt[i] += q[i];
+      }
+    };
+    float dot = 0.f, sg = 0.f;
+    for (int j = threadIdx.x; j < nvec; j += kBlock) {
+      float yv[V], gt[V], gq[V];
+      if (soft) {
+        load_vec<T, V>(y + row * y_stride + (int64_t)j * V, yv);
+        upstream(j, gt);
+#pragma unroll
+        for (int i = 0; i < V; ++i) dot += gt[i] * yv[i];
+      }
+      if (glq) {
+        load_vec<T, V>(glq + row * (int64_t)K + (int64_t)j * V, gq);
+#pragma unroll
+        for (int i = 0; i < V; ++i) sg += gq[i];
+      }
+    }
+    if (soft) dot = row_sum(dot, kBlock);
+    if (glq) sg = row_sum(sg, kBlock);
+    for (int j = threadIdx.x; j < nvec; j += kBlock) {
+      float yv[V], gt[V], q[V], gq[V], o[V];
+#pragma unroll
+      for (int i = 0; i < V; ++i) o[i] = 0.f;
+      if (soft) {
+        load_vec<T, V>(y + row * y_stride + (int64_t)j * V, yv);
+        upstream(j, gt);
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[i] += itau * yv[i] * (gt[i] - dot);
+      }
+      if (glq) {
+        load_vec<T, V>(lq + row * (int64_t)K + (int64_t)j * V, q);
+        load_vec<T, V>(glq + row * (int64_t)K + (int64_t)j * V, gq);
+#pragma unroll
+        for (int i = 0; i < V; ++i) o[i] += gq[i] - exp_acc(q[i]) * sg;
+      }
+      store_vec<T, V>(glogits + row * gl_stride + (int64_t)j * V, o);
+    }
+  }
+}
+
+template <typename T, int V, bool BWD>
+__global__ __launch_bounds__(kBlock) void categorical_kl_long_kernel(
+    const T* __restrict__ a, int64_t stride_a, const T* __restrict__ b, int64_t stride_b, const T* __restrict__ gkl,
+    T* __restrict__ kl, T* __restrict__ ga, T* __restrict__ gb, int64_t B, int K) {
+  const int nvec = K / V;
+  for (int64_t row = blockIdx.x; row < B; row += gridDim.x) {
+    const T* ar = a + row * stride_a;
+    const T* br = b + row * stride_b;
+    float ma = kNegInf, mb = kNegInf;
+    for (int j = threadIdx.x; j < nvec; j += kBlock) {
+      float va[V], vb[V];
+      load_vec<T, V>(ar + (int64_t)j * V, va);
+      load_vec<T, V>(br + (int64_t)j * V, vb);
+#pragma unroll
+      for (int i = 0; i < V; ++i) { ma = fmaxf(ma, va[i]); mb = fmaxf(mb, vb[i]); }
+    }
+    ma = row_max(ma, kBlock);
+    mb = row_max(mb, kBlock);
+    float sa = 0.f, sb = 0.f;
+    for (int j = threadIdx.x; j < nvec; j += kBlock) {
+      float va[V], vb[V];
+      load_vec<T, V>(ar + (int64_t)j * V, va);
+      load_vec<T, V>(br + (int64_t)j * V, vb);
+#pragma unroll
+      for (int i = 0; i < V; ++i) { sa += exp_acc(va[i] - ma); sb += exp_acc(vb[i] - mb); }
+    }
+    sa = row_sum(sa, kBlock);
+    sb = row_sum(sb, kBlock);
+    const float lsa = ma + logf(sa), lsb = mb + logf(sb);
+    const float ia = rcp_nr(sa), ib = rcp_nr(sb);
+    float s = 0.f;
+    for (int j = threadIdx.x; j < nvec; j += kBlock) {
+      float va[V], vb[V];
+      load_vec<T, V>(ar + (int64_t)j * V, va);
+      load_vec<T, V>(br + (int64_t)j * V, vb);
+#pragma unroll
+      for (int i = 0; i < V; ++i) s += exp_acc(va[i] - ma) * ia * ((va[i] - lsa) - (vb[i] - lsb));
+    }
+    s = row_sum(s, kBlock);
+    if constexpr (!BWD) {
+      if (threadIdx.x == 0) kl[row] = from_f32<T>(s);
+    } else {
+      const float gk = to_f32(gkl[row]);
+      for (int j = threadIdx.x; j < nvec; j += kBlock) {
+        float va[V], vb[V], oa[V], ob[V];
+        load_vec<T, V>(ar + (int64_t)j * V, va);
+        load_vec<T, V>(br + (int64_t)j * V, vb);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const float p = exp_acc(va[i] - ma) * ia;
+          oa[i] = gk * p * (((va[i] - lsa) - (vb[i] - lsb)) - s);
+          ob[i] = gk * (exp_acc(vb[i] - mb) * ib - p);
+        }
+        store_vec<T, V>(ga + row * (int64_t)K + (int64_t)j * V, oa);
+        if (gb) store_vec<T, V>(gb + row * (int64_t)K + (int64_t)j * V, ob);
+      }
+    }
+  }
+}
+
+constexpr int kLongRowGrid = 8192;   // blocks of a long-row launch (one row each, grid-strided beyond)
+
 template <typename T>
 static int gumbel_fwd_dispatch(const void* logits, int64_t row_stride, const void* unif, void* y, int64_t ys, void* zh,
                                int64_t zs, void* lq,
@@ -320,7 +538,16 @@ static int gumbel_fwd_dispatch(const void* logits, int64_t row_stride, const voi
                    aligned16(y) && aligned16(zh) &&
                    aligned16(lq) && (!unif || aligned16(unif));
   RowGeom g;
-  if (!row_geom_resident(B, vec ? K / VN : K, kGridStream, &g)) return VAE_ERR_ARG;
+  if (!row_geom_resident(B, vec ? K / VN : K, kGridStream, &g)) {
+    const int grid = (int)(B < kLongRowGrid ? B : kLongRowGrid);
+    if (vec)
+      hipLaunchKernelGGL((gumbel_fwd_long_kernel<T, VN>), dim3(grid), dim3(kBlock), 0, stream, (const T*)logits,
+                         row_stride, (const T*)unif, (T*)y, ys, (T*)zh, zs, (T*)lq, B, (int)K, tau, seed, offset, row0);
+    else
+      hipLaunchKernelGGL((gumbel_fwd_long_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, stream, (const T*)logits,
+                         row_stride, (const T*)unif, (T*)y, ys, (T*)zh, zs, (T*)lq, B, (int)K, tau, seed, offset, row0);
+    return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+  }
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gumbel_fwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
                                          (const T*)logits, row_stride, (const T*)unif, (T*)y, ys, (T*)zh, zs, (T*)lq, B,
@@ -341,7 +568,18 @@ static int gumbel_bwd_dispatch(const void* y, int64_t ys, const void* lq, const 
                    aligned16(y) && aligned16(lq) && aligned16(glogits) && (!gy || aligned16(gy)) &&
                    (!gzh || aligned16(gzh)) && (!glq || aligned16(glq));
   RowGeom g;
-  if (!row_geom_resident(B, vec ? K / VN : K, kGridStream, &g)) return VAE_ERR_ARG;
+  if (!row_geom_resident(B, vec ? K / VN : K, kGridStream, &g)) {
+    const int grid = (int)(B < kLongRowGrid ? B : kLongRowGrid);
+    if (vec)
+      hipLaunchKernelGGL((gumbel_bwd_long_kernel<T, VN>), dim3(grid), dim3(kBlock), 0, stream, (const T*)y, ys,
+                         (const T*)lq, (const T*)gy, gys, (const T*)gzh, gzs, (const T*)glq, (T*)glogits, gls, B, (int)K,
+                         tau);
+    else
+      hipLaunchKernelGGL((gumbel_bwd_long_kernel<T, 1>), dim3(grid), dim3(kBlock), 0, stream, (const T*)y, ys,
+                         (const T*)lq, (const T*)gy, gys, (const T*)gzh, gzs, (const T*)glq, (T*)glogits, gls, B, (int)K,
+                         tau);
+    return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+  }
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gumbel_bwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
                                          (const T*)y, ys, (const T*)lq, (const T*)gy, gys, (const T*)gzh, gzs,
@@ -361,7 +599,16 @@ static int cat_kl_dispatch(const void* a, int64_t sa, const void* b, int64_t sb,
   bool vec = (K % VN == 0) && (sa % VN == 0) && (sb % VN == 0) && aligned16(a) && aligned16(b);
   if (BWD) vec = vec && aligned16(ga) && (!gb || aligned16(gb));
   RowGeom g;
-  if (!row_geom_resident(B, vec ? K / VN : K, kGridStream, &g)) return VAE_ERR_ARG;
+  if (!row_geom_resident(B, vec ? K / VN : K, kGridStream, &g)) {
+    const int grid = (int)(B < kLongRowGrid ? B : kLongRowGrid);
+    if (vec)
+      hipLaunchKernelGGL((categorical_kl_long_kernel<T, VN, BWD>), dim3(grid), dim3(kBlock), 0, stream, (const T*)a, sa,
+                         (const T*)b, sb, (const T*)gkl, (T*)kl, (T*)ga, (T*)gb, B, (int)K);
+    else
+      hipLaunchKernelGGL((categorical_kl_long_kernel<T, 1, BWD>), dim3(grid), dim3(kBlock), 0, stream, (const T*)a, sa,
+                         (const T*)b, sb, (const T*)gkl, (T*)kl, (T*)ga, (T*)gb, B, (int)K);
+    return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+  }
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((categorical_kl_kernel<T, VN, U, BWD>), dim3(g.grid), dim3(kBlock), 0,
                                          stream, (const T*)a, sa, (const T*)b, sb, (const T*)gkl, (T*)kl, (T*)ga,
@@ -384,7 +631,7 @@ int vae_gumbel_fwd(const void* logits, int64_t row_stride, const void* unif, voi
                    int64_t z_hard_stride, void* log_q_z,
                    int64_t B, int64_t K, float tau, uint64_t seed, uint64_t offset, int64_t row0, int dtype,
                    vae_stream_t stream) {
-  if (B < 0 || K <= 0 || K > VAE_MAX_SOFTMAX_ROW || !(tau > 0.f)) return VAE_ERR_ARG;
+  if (B < 0 || K <= 0 || K > VAE_MAX_ROW || !(tau > 0.f)) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
   if (y_stride == 0) y_stride = K;
   if (z_hard_stride == 0) z_hard_stride = K;
@@ -405,7 +652,7 @@ int vae_gumbel_fwd(const void* logits, int64_t row_stride, const void* unif, voi
 int vae_gumbel_bwd(const void* y, int64_t y_stride, const void* log_q_z, const void* gy, int64_t gy_stride,
                    const void* gz_hard, int64_t gz_hard_stride, const void* glog_q_z, void* glogits,
                    int64_t glogits_stride, int64_t B, int64_t K, float tau, int dtype, vae_stream_t stream) {
-  if (B < 0 || K <= 0 || K > VAE_MAX_SOFTMAX_ROW || !(tau > 0.f)) return VAE_ERR_ARG;
+  if (B < 0 || K <= 0 || K > VAE_MAX_ROW || !(tau > 0.f)) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
   if (y_stride == 0) y_stride = K;
   if (gy_stride == 0) gy_stride = K;
@@ -425,7 +672,7 @@ int vae_gumbel_bwd(const void* y, int64_t y_stride, const void* log_q_z, const v
 
 int vae_categorical_kl_fwd(const void* log_q, int64_t stride_q, const void* log_p, int64_t stride_p, void* kl,
                            int64_t B, int64_t K, int dtype, vae_stream_t stream) {
-  if (B < 0 || K <= 0 || K > VAE_MAX_SOFTMAX_ROW) return VAE_ERR_ARG;
+  if (B < 0 || K <= 0 || K > VAE_MAX_ROW) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
   if (!log_q || !log_p || !kl || stride_q < K || stride_p < K) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -440,7 +687,7 @@ int vae_categorical_kl_fwd(const void* log_q, int64_t stride_q, const void* log_
 
 int vae_categorical_kl_bwd(const void* log_q, int64_t stride_q, const void* log_p, int64_t stride_p, const void* gkl,
                            void* g_log_q, void* g_log_p, int64_t B, int64_t K, int dtype, vae_stream_t stream) {
-  if (B < 0 || K <= 0 || K > VAE_MAX_SOFTMAX_ROW) return VAE_ERR_ARG;
+  if (B < 0 || K <= 0 || K > VAE_MAX_ROW) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
   if (!log_q || !log_p || !gkl || !g_log_q || stride_q < K || stride_p < K) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;

@@ -1269,6 +1269,9 @@ def bnflow(x, log_gamma, beta, running_mean=None, running_var=None, logdet_in=No
     x = x.contiguous()
     ld = None if logdet_in is None else logdet_in.reshape(-1).contiguous()
     F = x.shape[1]
+    if log_gamma.numel() != F or beta.numel() != F or (not training and (running_mean.numel() != F or
+                                                                         running_var.numel() != F)):
+        raise ValueError("bnflow: the parameter vectors must have x.shape[1] = %d entries" % F)
     mi = None if training else running_mean.float().contiguous()
     vi = None if training else running_var.float().contiguous()
     y, ldo, stats = _BNFlow.apply(x, log_gamma, beta, mi, vi, ld, float(eps), bool(training), bool(reverse),
