@@ -170,15 +170,20 @@ def main():
     overlap = dist is not None and backend == 'nccl' and os.environ.get('BENCH_SYNC_ALLREDUCE', '0') != '1'
     pending = [None]
     step_no = [1]   # Philox call offset: a fresh draw every step, the same one in that step's backward
+    rng_cell = [None]   # graph replay with in-kernel draws: the offset lives in this device word (vae_rng_next)
 
     def step(ev=None):
         def mark(i):
             if ev is not None:
                 ev[i].record()
         ws, st = wsst
+        off = step_no[0]
+        if rng_cell[0] is not None:
+            call('vae_rng_next', ptr(rng_cell[0]), 1, st)
+            off = (1 << 63) | rng_cell[0].data_ptr()          # VAE_OFFSET_ON_DEVICE
         mark(0)
         call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, noise_arg[0], ptr(z), L, plogvar, ptr(kl), pmeans,
-             ptr(ws), B, L, 1e-6, mean_scale, 1, 1234, step_no[0], row0, 0, st)
+             ptr(ws), B, L, 1e-6, mean_scale, 1, 1234, off, row0, 0, st)
         mark(1)
         if fused:
             call('vae_nll_elbo_fused', ptr(x), ptr(recon), 0, ptr(kl), None, None, 1.0, inv_count, 1.0, ptr(nll),
@@ -204,7 +209,7 @@ def main():
                  ptr(grecon), ptr(gkld), None, None, B, D, 0, st)
         mark(4)
         call('vae_gauss_reparam_kl_bwd', ptr(logits), 2 * L, noise_arg[0], ptr(gz), L, None, ptr(gkld), None,
-             ptr(glogits), 2 * L, B, L, 1e-6, mean_scale, 1, 1234, step_no[0], row0, 0, st)
+             ptr(glogits), 2 * L, B, L, 1e-6, mean_scale, 1, 1234, off, row0, 0, st)
         mark(5)
         if pending[0] is not None:
             pending[0].wait()                 # the launch stream waits for the collective; no host block
@@ -295,29 +300,38 @@ def main():
             philox_variant['kernels'][n] = {'avg_ms': round(ms, 5), 'algorithmic_bytes': ab2[n],
                                             'frac': round(ab2[n] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
-    # the same launches recorded once into a HIP graph and replayed (injected noise only: a graph would freeze the
-    # Philox offset): what the launch gaps between the four kernels cost.  Reported beside the figure.
+    # the same launches recorded once into a HIP graph and replayed: what the launch gaps between the four kernels
+    # cost.  Once with the injected noise, once with in-kernel Philox draws whose call offset lives in a device word
+    # that a one-thread node of the graph advances (vae_rng_next), so every replay draws fresh noise.
     graph_replay = None
     if world == 1 and not philox and not args.main_only:
+        graph_replay = {}
         side = torch.cuda.Stream(device=dev)
-        with torch.cuda.stream(side):
-            wsst[0], wsst[1] = _lib.workspace(dev), _lib.stream_ptr(dev)
-            step()                                   # warm the side stream's workspace outside the capture
-        torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
-            wsst[1] = _lib.stream_ptr(dev)
-            step()
-        for _ in range(args.warmup):
-            graph.replay()
-        torch.cuda.synchronize(dev)
-        t2 = time.perf_counter()
-        for _ in range(args.steps):
-            graph.replay()
-        torch.cuda.synchronize(dev)
-        dt3 = time.perf_counter() - t2
+        cell = torch.zeros(1, dtype=torch.int64, device=dev)
+        for label in ('injected', 'philox'):
+            noise_arg[0] = ptr(noise) if label == 'injected' else None
+            rng_cell[0] = None if label == 'injected' else cell
+            with torch.cuda.stream(side):
+                wsst[0], wsst[1] = _lib.workspace(dev), _lib.stream_ptr(dev)
+                step()                                   # warm the side stream's workspace outside the capture
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                wsst[1] = _lib.stream_ptr(dev)
+                step()
+            for _ in range(args.warmup):
+                graph.replay()
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                graph.replay()
+            torch.cuda.synchronize(dev)
+            dt3 = time.perf_counter() - t2
+            graph_replay[label] = {'value': B * args.steps / dt3, 'unit': 'samples/s',
+                                   'ms_per_step': dt3 / args.steps * 1e3}
+            del graph
         wsst[0], wsst[1] = ws, st
-        graph_replay = {'value': B * args.steps / dt3, 'unit': 'samples/s', 'ms_per_step': dt3 / args.steps * 1e3}
+        noise_arg[0], rng_cell[0] = ptr(noise), None
 
     # the same step through the drop-in classes (autograd Functions, torch allocator): not the timed region,
     # reported beside it so the cost of the Python boundary is visible

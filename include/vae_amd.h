@@ -62,6 +62,21 @@ size_t vae_workspace_bytes(void);
  * the summation order of the batch means.                                                         */
 int vae_tuning_set(const char* name, int64_t value);
 
+/* In-kernel Philox draws under HIP graph capture.  Every entry point that draws noise takes (seed, offset); the
+ * noise of element (row, col) is Philox4x32-10 keyed by (seed, offset, row0 + row, col), `offset` a call counter the
+ * caller advances.  A host value recorded into a HIP graph would repeat the same draw on every replay, so `offset`
+ * may instead be  VAE_OFFSET_ON_DEVICE | (address of a uint64 device word)  : the kernels read the counter from
+ * that word.  vae_rng_next writes such a word from a per-GPU counter held by the library (VAE_GRAPH_OFFSET_BASE +
+ * calls so far + 1: disjoint from host counters) and advances the counter by n (n draws: offset, offset + 1, ...);
+ * recorded into the graph in front of the drawing kernel it hands every replay a fresh offset, and the backward
+ * kernel, given the same word, regenerates that replay's noise.  The word must stay allocated while the graph
+ * lives.  vae_rng_reset zeroes the per-GPU counter (reproducible runs).  No reference counterpart: the reference
+ * draws with torch's generator (isotropic_gaussian.py:88, gumbel.py:269).                                    */
+#define VAE_OFFSET_ON_DEVICE (1ull << 63)
+#define VAE_GRAPH_OFFSET_BASE (1ull << 62)
+int vae_rng_next(uint64_t* cell, int64_t n, vae_stream_t stream);
+int vae_rng_reset(vae_stream_t stream);
+
 /* "Saw a NaN" word (replaces the per-step host check nan_check_and_break of abstract_vae.py:366-369,
  * isotropic_gaussian.py:89-90, vrnn.py:427-428, which synchronises the stream on every step).  The closing wave of
  * every kernel that finishes batch means ORs VAE_NAN_* bits into one word of `workspace` when a mean comes out NaN

@@ -1,7 +1,8 @@
 """HIP graph capture of the hot path through the drop-in classes: every launch is asynchronous on torch's
 current stream, nothing synchronises or allocates outside torch's (capturable) allocator, so a whole
-forward + loss + backward records into one graph.  Draws made while capturing come from torch's graph-aware
-generator (vae_amd.rng.captured_noise), so every replay gets fresh noise.
+forward + loss + backward records into one graph.  Draws made while capturing stay in-kernel Philox draws: their
+call offset lives in a device word that a one-thread node of the graph advances (vae_rng_next, vae_amd/rng.py), so
+every replay gets fresh noise and the backward kernels regenerate exactly the noise of their replay.
 
 Checked: replayed outputs equal the oracle evaluated on the noise recovered from the replay's own z;
 two replays draw different noise; the replayed gradients match the oracle's."""
@@ -66,6 +67,18 @@ def test_graph_capture_gaussian_elbo_step():
         (g0,) = torch.autograd.grad(r0['loss_mean'], lc)
         close(g, g0, rtol=1e-4, atol=1e-6)
     assert not torch.equal(seen[0], seen[1])            # fresh noise on every replay
+    # reproducible: restarting the counters replays the same sequence of draws
+    import vae_amd
+    vae_amd.rng.manual_seed(11)
+    graph.replay()
+    za = z.detach().clone()
+    graph.replay()
+    zb = z.detach().clone()
+    vae_amd.rng.manual_seed(11)
+    graph.replay()
+    assert torch.equal(z, za) and not torch.equal(za, zb)
+    # no draw was materialised: the graph holds no torch.randn node's [B, L] buffer (the draw is in-kernel)
+    assert len(vae_amd.rng._cells) >= 1
 
 
 def test_graph_capture_gumbel_and_vrnn_pair():

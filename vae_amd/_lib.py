@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the CDLL below, see module 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VAE_AMD_LIB') or os.path.join(_HERE, 'libvae_amd.so')  # env override: tuning builds only
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 VAE_OK, VAE_ERR_ARG, VAE_ERR_LAUNCH = 0, 1, 2
 VAE_F32, VAE_BF16, VAE_F16 = 0, 1, 2
@@ -27,6 +27,8 @@ _pp = ctypes.POINTER(ctypes.c_void_p)   # host array of device pointers
 SIGNATURES = {
     'vae_abi_version': [],
     'vae_workspace_bytes': [],
+    'vae_rng_next': [_p, _i64, _p],
+    'vae_rng_reset': [_p],
     'vae_nan_flag': [_p, _i, ctypes.POINTER(ctypes.c_uint32), _p],
     'vae_tuning_set': [ctypes.c_char_p, _i64],
     'vae_gauss_reparam_kl_fwd': [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i64, _i64, _f, _f, _i, _u64, _u64, _i64, _i,

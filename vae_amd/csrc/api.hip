@@ -5,8 +5,32 @@
 #include "common.hpp"
 #include "../../include/vae_amd.h"
 
+namespace {
+// Philox call offsets for draws recorded into HIP graphs: one counter per GPU (a file-scope __device__ word: every
+// device the library runs on has its own), advanced by a one-thread node of the graph itself.
+__device__ unsigned long long g_graph_calls;
+__global__ void rng_next_kernel(unsigned long long* cell, unsigned long long n) {
+  // read past the scalar cache: the previous node that wrote the counter may have run a microsecond ago
+  const unsigned long long c = __hip_atomic_load(&g_graph_calls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  *cell = VAE_GRAPH_OFFSET_BASE + c + 1ull;
+  g_graph_calls = c + n;
+}
+__global__ void rng_reset_kernel() { g_graph_calls = 0ull; }
+}  // namespace
+
 extern "C" {
-int vae_abi_version(void) { return 9; }
+int vae_abi_version(void) { return 10; }
+
+int vae_rng_next(uint64_t* cell, int64_t n, vae_stream_t stream) {
+  if (!cell || n < 1) return VAE_ERR_ARG;
+  hipLaunchKernelGGL(rng_next_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)cell,
+                     (unsigned long long)n);
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+int vae_rng_reset(vae_stream_t stream) {
+  hipLaunchKernelGGL(rng_reset_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream);
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
 // counters + group partials + one partial per block x up to 8 scalars (common.hpp, grid_reduce)
 size_t vae_workspace_bytes(void) { return vae::kWorkspaceFloats * sizeof(float); }
 

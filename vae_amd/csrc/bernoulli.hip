@@ -37,6 +37,7 @@ __global__ __launch_bounds__(kBlock) void bernoulli_fwd_kernel(
     const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ unif, T* __restrict__ y_out,
     int64_t y_stride, T* __restrict__ zh_out, int64_t zh_stride, int64_t B, int K, float tau, uint64_t seed, uint64_t offset, int64_t row0, int G,
     int64_t tiles) {
+  offset = resolve_offset(offset);
   const int rpb = kBlock / G;
   const bool nts = nt_stores((int64_t)B * K * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;

@@ -596,6 +596,16 @@ __device__ __forceinline__ void philox_uniform(uint64_t seed, uint64_t stream, u
   }
 }
 
+// A Philox call offset is a host value, or -- with bit 63 set -- the address of a uint64 device word that holds it
+// (VAE_OFFSET_ON_DEVICE, include/vae_amd.h: a HIP graph would freeze a host value into every replay; the word is
+// written by vae_rng_next, itself a node of the graph).  Read past the scalar cache (sc1 vector load).
+__device__ __forceinline__ uint64_t resolve_offset(uint64_t offset) {
+  if (offset >> 63)
+    return __hip_atomic_load(reinterpret_cast<const uint64_t*>(offset & ~(1ull << 63)), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+  return offset;
+}
+
 // ---- host-side launch geometry -------------------------------------------------
 // Tuning overrides, read from the environment ONCE (first launch) and settable in-process through
 // vae_tuning_set (scripts/ab.py); 0 = the built-in choice.

@@ -32,6 +32,7 @@ __global__ __launch_bounds__(kBlock) void gauss_fwd_kernel(
     const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ noise, T* __restrict__ z,
     int64_t z_stride, T* __restrict__ s_out, T* __restrict__ kl, float* __restrict__ ws, float mean_scale,
     float* __restrict__ means, int64_t B, int L, float eps_tol, int training, uint64_t seed, uint64_t offset, int64_t row0, int G, int64_t tiles) {
+  offset = resolve_offset(offset);
   const int rpb = kBlock / G;
   const bool nts = nt_stores((int64_t)B * L * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(kBlock) void gauss_bwd_kernel(
     int64_t gz_stride, const T* __restrict__ gs, const T* __restrict__ gkl, const float* __restrict__ gmeans,
     T* __restrict__ glogits, int64_t gl_stride, int64_t B, int L, float eps_tol, float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0,
     int G, int64_t tiles) {
+  offset = resolve_offset(offset);
   const int rpb = kBlock / G;
   const bool nts = nt_stores((int64_t)B * L * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;

@@ -25,6 +25,7 @@ __global__ __launch_bounds__(kBlock) void gauss_pair_fwd_kernel(
     T* __restrict__ lv_q, T* __restrict__ lv_p, T* __restrict__ clamped, T* __restrict__ kl_pair,
     T* __restrict__ kl_prior, float* __restrict__ ws, float mean_scale, float* __restrict__ means, int64_t B, int L,
     float eps_tol, int training, uint64_t seed, uint64_t offset, int64_t row0, int G, int64_t tiles) {
+  offset = resolve_offset(offset);
   const int rpb = kBlock / G;
   const bool nts = nt_stores((int64_t)B * L * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(kBlock) void gauss_pair_bwd_kernel(
     const T* __restrict__ gclamped, const T* __restrict__ gkl_pair, const T* __restrict__ gkl_prior,
     const float* __restrict__ gmeans, T* __restrict__ g_enc, T* __restrict__ g_pri, int64_t B, int L, float eps_tol,
     float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0, int G, int64_t tiles) {
+  offset = resolve_offset(offset);
   const int rpb = kBlock / G;
   const bool nts = nt_stores((int64_t)B * L * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;

@@ -63,8 +63,6 @@ class Bernoulli(nn.Module):
             self.tau = np.clip(updated_tau, self.clip_min, self.max_temp)
 
     def reparmeterize(self, logits, noise=None, want_hard=True):
-        if noise is None:
-            noise = rng.captured_noise('uniform', logits.shape, logits)   # None unless a HIP graph is capturing
         seed, offset = (0, 0) if noise is not None else rng.next_call()
         return F_.relaxed_bernoulli(logits, unif=noise, tau=float(self.tau), seed=seed, offset=offset,
                                     row0=self.row_offset, want_hard=want_hard)

@@ -54,11 +54,6 @@ class ConcatReparameterizer(nn.Module):
         into one shared d(logits) buffer.  Same returns as the generic path below."""
         training = bool(self.training or force)
         specs, seeds = [], []
-        if rng.capturing():   # graph capture: torch draws (see rng.captured_noise)
-            noise = [n if n is not None else (
-                (rng.captured_noise('normal', (logits.shape[0], c.output_size), logits) if training else None)
-                if isinstance(c, IsotropicGaussian) else rng.captured_noise('uniform', (logits.shape[0], c.output_size), logits))
-                for c, n in zip(self.reparameterizers, noise)]
         for child, n in zip(self.reparameterizers, noise):
             if isinstance(child, IsotropicGaussian):
                 specs.append(('gauss', child.output_size, child.eps_tol, child.mean_scale))

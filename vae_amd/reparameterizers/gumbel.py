@@ -59,8 +59,6 @@ class GumbelSoftmax(nn.Module):
 
     def reparmeterize(self, logits, noise=None, want=(True, True, True)):
         assert self.dim in (-1, logits.dim() - 1), "the HIP path reduces over the last dim"
-        if noise is None:
-            noise = rng.captured_noise('uniform', logits.shape, logits)   # None unless a HIP graph is capturing
         seed, offset = (0, 0) if noise is not None else rng.next_call()
         return F_.gumbel_softmax(logits, unif=noise, tau=float(self.tau), seed=seed, offset=offset,
                                  row0=self.row_offset, want=want)

@@ -89,8 +89,6 @@ class IsotropicGaussian(nn.Module):
 
         seed, offset = (0, 0)
         if training and noise is None:
-            noise = rng.captured_noise('normal', (rows.shape[0], rows.shape[1] // 2), rows)   # None unless a HIP graph is capturing
-        if training and noise is None:
             seed, offset = rng.next_call()
         z, _, kl, means = F_.gauss_reparam_kl(rows, noise=noise, eps_tol=self.eps_tol, training=training, seed=seed,
                                               offset=offset, row0=self.row_offset, mean_scale=self.mean_scale,
@@ -121,8 +119,6 @@ class IsotropicGaussian(nn.Module):
             return [p[0] for p in pairs], [p[1] for p in pairs]
         L = self.output_size
         assert logits.shape[-1] == 2 * L, "feature_size = {} but requested output_size = {}".format(logits.shape[-1], L)
-        if noise is None:
-            noise = rng.captured_noise('normal', (S, logits.shape[0], L), logits)
         seed, offset = (0, 0) if noise is not None else rng.next_calls(S)
         z, _, kl, means = F_.gauss_reparam_multi(logits, S, noise=noise, eps_tol=self.eps_tol, seed=seed, offset=offset,
                                                  row0=self.row_offset, mean_scale=self.mean_scale, want_logvar=False)

@@ -57,8 +57,6 @@ def _reparameterize_fused(rep, logits_map, config, noise, force=False):
     assert enc.shape[-1] == 2 * L and pri.shape[-1] == 2 * L
     training = bool(rep.training or force)
     seed, offset = (0, 0)
-    if training and rng.capturing():   # graph capture: torch draws (see rng.captured_noise)
-        noise = tuple(n if n is not None else rng.captured_noise('normal', (enc.shape[0], L), enc) for n in noise)
     if training and (noise[0] is None or noise[1] is None):
         seed, offset = rng.next_call()
     z_q, z_p, _, _, clamped, kl_pair, kl_prior, means = F_.gauss_pair(
