@@ -231,6 +231,28 @@ def likelihood(B, K, L=64, D=784):
         rows.append({'kernel': name, 'config': 'B=%d K=%d L=%d D=%d' % (B, K, L, D), 'ms': round(ms, 3), 'draws': draws})
 
 
+def nll_steps(Tn, B, D):
+    """The VRNN loss over Tn steps (vrnn.py:805-829) through the step-table entry points: Tn separate [B, D] target and
+    reconstruction tensors read where they are (no torch.cat), and the same call through vae_amd.vrnn.loss_function."""
+    xs = [(T(B, D, kind='rand') < 0.3).float() for _ in range(Tn)]
+    rs = [T(B, D) for _ in range(Tn)]
+    gs = [T(B, D, kind='e') for _ in range(Tn)]
+    kld = T(Tn * B, kind='rand')
+    nll_, loss, elbo = T(Tn * B, kind='e'), T(Tn * B, kind='e'), T(Tn * B, kind='e')
+    la, ea, means = T(B, kind='e'), T(B, kind='e'), torch.zeros(6, device=dev)
+    gmeans = torch.zeros(6, device=dev)
+    gmeans[0] = 1
+    gkld = T(Tn * B, kind='e')
+    px, pr, pg = _lib.ptr_array(xs), _lib.ptr_array(rs), _lib.ptr_array(gs)
+    cfg = 'T=%d x B=%d D=%d bernoulli f32, %d tensors each side' % (Tn, B, D, Tn)
+    inv = 1.0 / (Tn * B)
+    timeit('nll_steps_elbo_fwd', cfg, lambda: call('vae_nll_steps_elbo_fwd', px, pr, Tn, 0, ptr(kld), 1.0, inv, ptr(nll_),
+                                                   ptr(loss), ptr(elbo), ptr(la), ptr(ea), None, ptr(means), ptr(ws), B, D,
+                                                   0, st), Tn * B * (8 * D + 16))
+    timeit('nll_steps_elbo_bwd', cfg, lambda: call('vae_nll_steps_elbo_bwd', px, pr, pg, Tn, 0, None, None, None,
+                                                   ptr(gmeans), 1.0, inv, ptr(gkld), B, D, 0, st), Tn * B * (12 * D + 4))
+
+
 def bernoulli(B, K):
     logits, U, gy = T(B, K), T(B, K, kind='rand'), T(B, K)
     y, zh, gl, kl, gkl = T(B, K, kind='e'), T(B, K, kind='e'), T(B, K, kind='e'), T(B, kind='e'), T(B)
@@ -375,6 +397,7 @@ if __name__ == '__main__':
     pair_fused(16384, 128)
     pair_fused(4096, 32)
     nll(64 * 1024, 784, 0, 'bernoulli T=64 x B=1024')
+    nll_steps(64, 1024, 784)
     print('== multi-sample forms (loss_function K > 1, MSGVAE, likelihood)')
     multi(65536, 512, 784, 4)
     multi(16384, 128, 784, 8)

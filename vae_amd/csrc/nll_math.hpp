@@ -176,9 +176,22 @@ __global__ __launch_bounds__(kBlock) void elbo_rows_means_kernel(const T* __rest
     const float inv_steps = div_rn(1.0f, (float)steps);
     for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < Bs; b += (int64_t)gridDim.x * kBlock) {
       float sl = to_f32(loss[b]), se = to_f32(elbo[b]);
-      for (int64_t t = 1; t < steps; ++t) {
-        sl = to_f32(from_f32<T>(add_rn(sl, to_f32(loss[t * Bs + b]))));
-        se = to_f32(from_f32<T>(add_rn(se, to_f32(elbo[t * Bs + b]))));
+      // eight steps' values requested together (the additions stay in step order: their roundings are the reference's)
+      for (int64_t t0 = 1; t0 < steps; t0 += 8) {
+        float vl[8], ve[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int64_t t = t0 + k < steps ? t0 + k : steps - 1;
+          vl[k] = to_f32(loss[t * Bs + b]);
+          ve[k] = to_f32(elbo[t * Bs + b]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if (t0 + k < steps) {
+            sl = to_f32(from_f32<T>(add_rn(sl, vl[k])));
+            se = to_f32(from_f32<T>(add_rn(se, ve[k])));
+          }
+        }
       }
       // tensor /= python_int on the device is a multiplication by the fp32 reciprocal in stock PyTorch (div_true
       // with a CPU scalar divisor): the same here
@@ -192,9 +205,11 @@ __global__ __launch_bounds__(kBlock) void elbo_rows_means_kernel(const T* __rest
     const int64_t Bs = B / steps;
     for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < Bs; b += (int64_t)gridDim.x * kBlock) {
       float m = to_f32(elbo[b]);
+#pragma unroll 8
       for (int64_t t = 1; t < steps; ++t) m = fmaxf(m, to_f32(elbo[t * Bs + b]));
       const float shift = (fabsf(m) == INFINITY) ? 0.0f : m;
       float s = 0.0f;
+#pragma unroll 8
       for (int64_t t = 0; t < steps; ++t) s += expf(to_f32(elbo[t * Bs + b]) - shift);
       elbo_lse[b] = from_f32<T>(logf(s) + shift);
     }
