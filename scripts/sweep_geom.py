@@ -24,6 +24,15 @@ cases = {
     'nll_bf16': lambda: bc.nll(65536, 784, 0, 'bernoulli', dtype=torch.bfloat16),
     'gauss_philox': lambda: bc.gauss(65536, 512, philox=True),
     'gauss_f32': lambda: bc.gauss(65536, 512),
+    'pair': lambda: bc.pair_fused(16384, 128),
+    'pair512': lambda: bc.pair_fused(65536, 512),
+    'pair64': lambda: bc.pair_fused(65536, 64),
+    'flow64': lambda: bc.flow(262144, 64),
+    'flow2048': lambda: bc.flow(16384, 2048),
+    'gauss_L128_B16k': lambda: bc.gauss(16384, 128),
+    'gumbel256': lambda: bc.gumbel(65536, 256),
+    'flow': lambda: bc.flow(65536, 512),
+    'bnflow': lambda: bc.flowtail(65536, 512),
     'gauss_f32_L1024': lambda: bc.gauss(65536, 1024),
     'gauss_f32_L256': lambda: bc.gauss(131072, 256),
     'gauss_f32_L128': lambda: bc.gauss(262144, 128),

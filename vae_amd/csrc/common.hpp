@@ -665,6 +665,19 @@ inline RowGeom row_geom(int64_t rows, int64_t vecs_per_row, int64_t max_grid = k
   return g;
 }
 
+// Another lane group / unroll for a geometry row_geom produced: the per-family rules found by the cold-cache sweeps
+// (scripts/sweep_geom.py, profiles/r02_geom_sweep.txt).  Leaves `g` alone while a tuning knob fixes G or U.
+inline void regroup(RowGeom& g, int64_t rows, int G, int U, int64_t max_grid) {
+  if (knobs().G || knobs().U) return;
+  if (g.grid < g.tiles) max_grid = g.grid;   // a cap row_geom took from the tuning knobs
+  g.G = G;
+  g.U = U;
+  g.rows_per_block = kBlock / G;
+  g.tiles = (rows + g.rows_per_block - 1) / g.rows_per_block;
+  g.grid = (int)(g.tiles < max_grid ? g.tiles : max_grid);
+  if (g.grid < 1) g.grid = 1;
+}
+
 // Geometry for kernels that keep a whole row in registers (softmax-class: several reductions over
 // the same row): the smallest lane group G (<= 64, else the whole block) with ceil(vecs/G) <= 4.
 // Returns false when the row does not fit (vecs > 4 * kBlock).

@@ -105,7 +105,9 @@ static int flow_fwd_dispatch(const void* u, const void* logdet, int64_t R, void*
   const int64_t row_len = cross_batch ? F : R * F;
   if (phase != 2) {
     const bool vec = (row_len % VN == 0) && aligned16(u);
-    const RowGeom g = row_geom(B, vec ? row_len / VN : row_len, kGridReduce);
+    RowGeom g = row_geom(B, vec ? row_len / VN : row_len, kGridReduce);
+    // load-only kernel: rows of 65..128 vectors run 16 rows per block, four chunks in flight (F = 512: 37.1 -> 29.3 us)
+    if ((vec ? row_len / VN : row_len) > 64 && (vec ? row_len / VN : row_len) <= 128) regroup(g, B, 16, 4, kGridReduce);
     const float scale = cross_batch ? 1.0f : 1.0f / (float)R;
     const float cadd = (float)F * kHalfLog2PiF;
     float* partials = cross_batch ? workspace : nullptr;

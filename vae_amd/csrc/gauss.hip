@@ -247,15 +247,7 @@ __global__ __launch_bounds__(kBlock) void gauss_kl_bwd_kernel(
 static RowGeom gauss_geom(int64_t B, int64_t vecs, int64_t max_grid, bool philox, bool fwd) {
   RowGeom g = row_geom(B, vecs, max_grid);
   if (knobs().G || knobs().U) return g;
-  if (fwd && vecs > 64 && vecs <= 128) {
-    if (g.grid < g.tiles) max_grid = g.grid;   // a cap row_geom took from the tuning knobs
-    g.G = 32;
-    g.U = 2;
-    g.rows_per_block = kBlock / g.G;
-    g.tiles = (B + g.rows_per_block - 1) / g.rows_per_block;
-    g.grid = (int)(g.tiles < max_grid ? g.tiles : max_grid);
-    if (g.grid < 1) g.grid = 1;
-  }
+  if (fwd && vecs > 64 && vecs <= 128) regroup(g, B, 32, 2, max_grid);
   if (philox && (fwd || vecs <= 128)) g.U = 1;
   return g;
 }

@@ -133,14 +133,7 @@ struct StepRows {
 inline RowGeom nll_geom(int64_t B, int64_t vecs_per_row, int64_t max_grid, bool long_rows_always = false,
                         bool loads_only = false) {
   RowGeom g = row_geom(B, vecs_per_row, max_grid);
-  if (loads_only && g.G == 64 && vecs_per_row <= 128 && knobs().G == 0 && knobs().U == 0) {
-    g.G = 32;
-    g.U = 4;
-    g.rows_per_block = kBlock / g.G;
-    g.tiles = (B + g.rows_per_block - 1) / g.rows_per_block;
-    g.grid = (int)(g.tiles < max_grid ? g.tiles : max_grid);
-    if (g.grid < 1) g.grid = 1;
-  }
+  if (loads_only && g.G == 64 && vecs_per_row <= 128) regroup(g, B, 32, 4, max_grid);
   if (vecs_per_row >= 1024 && (long_rows_always || g.tiles < 4 * 256)) {
     g.G = kBlock;
     g.U = 4;

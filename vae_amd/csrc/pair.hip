@@ -191,7 +191,14 @@ static int pair_fwd_dispatch(const void* enc, int64_t se, const void* pri, int64
   const bool vec = (L % VN == 0) && (se % VN == 0) && (sp % VN == 0) && aligned16(enc) && aligned16(pri) &&
                    (!lvq || aligned16(lvq)) && (!lvp || aligned16(lvp)) && aligned16(clamped) && (!nq || aligned16(nq)) &&
                    (!np || aligned16(np)) && (!zq || aligned16(zq)) && (!zp || aligned16(zp));
-  const RowGeom g = row_geom(B, vec ? L / VN : L, means ? kGridReduce : kGridStream);
+  RowGeom g = row_geom(B, vec ? L / VN : L, means ? kGridReduce : kGridStream);
+  {
+    // r02 cold-cache sweep: the many live arrays of this kernel make one chunk in flight the better choice for short
+    // rows (L = 128: 26.1 -> 23.5 us), two rows per wave for rows of 65..128 vectors (L = 512: 247 -> 238 us)
+    const int64_t vecs = vec ? L / VN : L;
+    if (vecs >= 16 && vecs <= 32) regroup(g, B, 16, 1, means ? kGridReduce : kGridStream);
+    else if (vecs > 64 && vecs <= 128) regroup(g, B, 32, 2, means ? kGridReduce : kGridStream);
+  }
   float* ws = means ? workspace : nullptr;
   if (vec) {
     VAE_SWITCH_U(g.U < 4 ? g.U : 2,
