@@ -470,7 +470,7 @@ def whole_model_leg(dev, x_img, B, world, fence, all_reduce_max, steps=10, warmu
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         all_reduce_max(t, op=tdist.ReduceOp.MAX)
         dt = float(t.item())
-    val = float(last)
+    val = float(last.detach())
     grad_bytes = flat.nbytes
     del model, flat, opt
     torch.cuda.empty_cache()

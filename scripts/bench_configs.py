@@ -159,6 +159,27 @@ def concat_module(B, L, K):
             logits.grad = None
         timeit(label, 'B=%d L=%d K=%d f32 module fwd+kl+bwd (+ torch z*w sum)' % (B, L, K), fn, nbytes)
     C._FUSABLE = fusable
+    # the same one-node step with in-kernel Philox draws, eager and replayed from one HIP graph (the step is
+    # host-bound eager: ~135 us of Python and autograd around ~130 us of kernels)
+    m = ConcatReparameterizer(['isotropic_gaussian', 'discrete'], dict(cfgd)).train()
+
+    def fn2():
+        z, params = m(logits)
+        ((z * w).sum() + m.kl(params).sum()).backward()
+        logits.grad = None
+    nb2 = nbytes - B * 4 * (L + K + L)       # no noise tensors read
+    cfg2 = 'B=%d L=%d K=%d f32 module fwd+kl+bwd, in-kernel noise' % (B, L, K)
+    timeit('concat step (eager)', cfg2, fn2, nb2)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            fn2()
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fn2()
+    timeit('concat step (HIP graph)', cfg2, graph.replay, nb2)
 
 
 def multi(B, L, D, S):

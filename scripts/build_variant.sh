@@ -1,6 +1,6 @@
 #!/bin/bash
 # Tuning aid: build a variant of the library with extra -D flags into vae_amd/libvae_amd_<tag>.so
-#   scripts/build_variant.sh nts -DVAE_NT_STORE=1
+#   scripts/build_variant.sh allnt -DVAE_NT_STORE_MIN_BYTES=0
 set -e
 tag=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
