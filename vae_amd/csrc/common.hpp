@@ -257,14 +257,33 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Sum / max over the G lanes that share a row (G power of two, <= 64).  After the
-// butterfly every lane of the group holds the result.
+// One DPP step (v_mov_b32_dpp: a cross-lane read inside a 16-lane row at VALU speed, ~10 cycles, where a ds_bpermute
+// butterfly step is an LDS round trip of ~120).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+
+// Sum / max over the G lanes that share a row (G power of two, <= 64; every lane of the wave takes part: the call
+// sites are in block-uniform control flow).  Butterfly: xor 1 and xor 2 inside the quads, then the half-row and row
+// mirrors (the sub-groups they pair already hold equal values) by DPP; the 16- and 32-lane levels by ds_bpermute.
+// After it every lane of the group holds the result, the same bits in all of them.
 __device__ __forceinline__ float group_sum(float v, int G) {
-  for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if (G >= 2) v += dpp_f<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+  if (G >= 4) v += dpp_f<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+  if (G >= 8) v += dpp_f<0x141, 0xf>(v);   // row_half_mirror
+  if (G >= 16) v += dpp_f<0x140, 0xf>(v);  // row_mirror
+  if (G >= 32) v += __shfl_xor(v, 16, 64);
+  if (G >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
 __device__ __forceinline__ float group_max(float v, int G) {
-  for (int o = G >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if (G >= 2) v = fmaxf(v, dpp_f<0xB1, 0xf>(v));
+  if (G >= 4) v = fmaxf(v, dpp_f<0x4E, 0xf>(v));
+  if (G >= 8) v = fmaxf(v, dpp_f<0x141, 0xf>(v));
+  if (G >= 16) v = fmaxf(v, dpp_f<0x140, 0xf>(v));
+  if (G >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+  if (G >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
 __device__ __forceinline__ float wave_sum(float v) { return group_sum(v, 64); }
@@ -301,10 +320,6 @@ __device__ __forceinline__ float row_max(float v, int G) {
 // ~120): xor 1, xor 2 inside quads, half-mirror and mirror inside the 16-lane rows, then row_bcast15 / row_bcast31
 // carry the row totals up; lane 63 holds the sum of all 64 lanes in a fixed order and every lane gets it back through
 // a readlane.  All 64 lanes must be active.  Used where a latency chain ends in these sums (the closing blocks).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
-}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_d(double v) {
   const uint64_t b = __builtin_bit_cast(uint64_t, v);
