@@ -18,6 +18,7 @@ import sys
 import types
 import importlib.util
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.distributions as D
@@ -652,6 +653,70 @@ def make_flowtail(vae, out):
             'log_probs_second_train_call': lp, 'u_eval': ue, 'logdet_eval': lde})
 
 
+def make_glow(vae, out):
+    """The glow-side layers of flows/__init__.py run by the reference itself: ActNorm (data-dependent first call),
+    InvertibleMM, LUInvertibleMM, Shuffle, and two-block glow / maf_split_glow stacks (flows/__init__.py:274-389,
+    612-625, 651-673), forward, inverse and gradients."""
+    FL = sys.modules['models.vae.flows']
+    B, Fd, Hd = 8, 6, 16
+
+    def sd(m):
+        return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    def grads(outs, ws, inputs):
+        obj = sum((o * w).sum() for o, w in zip(outs, ws))
+        return [None if g is None else g.detach().clone() for g in torch.autograd.grad(obj, inputs, allow_unused=True)]
+
+    torch.manual_seed(1500)
+    x = torch.randn(B, Fd, requires_grad=True)
+    wu, wl = torch.randn(B, Fd), torch.randn(B, 1)
+
+    m = FL.ActNorm(Fd)
+    xs = (x * 1.7 + 0.4).detach().requires_grad_(True)
+    y, ld = m(xs)                                   # first call: weight / bias from the batch
+    after_init = sd(m)
+    y2, ld2 = m(x)                                  # second call: the parameters as they are
+    g = grads([y2, ld2], [wu, wl], [x, m.weight, m.bias])
+    xi, ldi = m(y2.detach(), mode='inverse')
+    out['glow_actnorm'] = detach_tree({'x_first': xs, 'y_first': y, 'logdet_first': ld, 'state_dict_after_init': after_init,
+                                       'x': x, 'wu': wu, 'wl': wl, 'y': y2, 'logdet': ld2, 'grad_x': g[0],
+                                       'grad_weight': g[1], 'grad_bias': g[2], 'x_inverse': xi, 'logdet_inverse': ldi})
+    m = FL.InvertibleMM(Fd)
+    y, ld = m(x)
+    g = grads([y, ld], [wu, wl], [x, m.W])
+    xi, ldi = m(y.detach(), mode='inverse')
+    out['glow_invmm'] = detach_tree({'x': x, 'wu': wu, 'wl': wl, 'state_dict': sd(m), 'y': y, 'logdet': ld, 'grad_x': g[0],
+                                     'grad_W': g[1], 'x_inverse': xi, 'logdet_inverse': ldi})
+    m = FL.LUInvertibleMM(Fd)
+    y, ld = m(x)
+    g = grads([y, ld], [wu, wl], [x, m.L, m.U, m.log_S])
+    xi, ldi = m(y.detach(), mode='inverse')
+    out['glow_lumm'] = detach_tree({'x': x, 'wu': wu, 'wl': wl, 'state_dict': sd(m), 'P': m.P, 'sign_S': m.sign_S, 'y': y,
+                                    'logdet': ld, 'grad_x': g[0], 'grad_L': g[1], 'grad_U': g[2], 'grad_log_S': g[3],
+                                    'x_inverse': xi, 'logdet_inverse': ldi})
+    m = FL.Shuffle(Fd)
+    y, ld = m(x)
+    xi, _ = m(y.detach(), mode='inverse')
+    out['glow_shuffle'] = detach_tree({'x': x, 'perm': torch.from_numpy(np.asarray(m.perm)).long(),
+                                       'inv_perm': torch.from_numpy(np.asarray(m.inv_perm)).long(), 'y': y, 'logdet': ld, 'x_inverse': xi})
+    for name, build in (('glow', lambda: FL.build_glow_flow(Fd, Hd, num_blocks=2, activation_str='relu',
+                                                            normalization_str='none', layer_modifier='none')),
+                        ('mafsplitglow', lambda: FL.build_maf_split_glow_flow(Fd, Hd, num_blocks=2))):
+        torch.manual_seed(1510)
+        m = build()
+        m.train(True)
+        before = sd(m)
+        u, ld = m(x)                                # ActNorm layers initialise themselves on this call
+        after = sd(m)
+        u2, ld2 = m(x)
+        params = [p for p in m.parameters()]
+        g = grads([u2, ld2], [wu, wl], [x] + params)
+        out['glow_stack_%s' % name] = detach_tree({
+            'x': x, 'wu': wu, 'wl': wl, 'state_dict_before': before, 'state_dict_after_first_call': after, 'u_first': u,
+            'logdet_first': ld, 'u': u2, 'logdet': ld2, 'grad_x': g[0], 'grad_params': g[1:],
+            'param_names': [k for k, _ in m.named_parameters()]})
+
+
 def main():
     vae = install_reference()
     out = {}
@@ -668,6 +733,7 @@ def main():
     make_mi(vae, out)
     make_conditioned(vae, out)
     make_flowtail(vae, out)
+    make_glow(vae, out)
     groups = {}
     for k, v in out.items():
         groups.setdefault(k.split('_')[0], {})[k] = v

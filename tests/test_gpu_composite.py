@@ -508,11 +508,10 @@ def test_flow_reparameterizer_builds_from_reference_config(golden):
     close(p['logdet'], g['logdet'], rtol=1e-5, atol=1e-5)
     close(m.kl(p), g['kl'], rtol=1e-5, atol=1e-5)
     assert m.input_size == 6 and m.output_size == 6
-    for ft in ('maf_split', 'realnvp'):
+    for ft in ('maf_split', 'realnvp', 'glow', 'maf_split_glow'):
         FlowReparameterizer(ref_cfg(continuous_size=6, flow_type=ft, dense_normalization='none'))
-    for ft in ('glow', 'maf_split_glow'):
-        with pytest.raises(NotImplementedError):
-            FlowReparameterizer(ref_cfg(flow_type=ft))
+    with pytest.raises(ValueError):
+        FlowReparameterizer(ref_cfg(flow_type='planar'))
 
 
 def test_sequential_gauss_flow_golden_end_to_end(golden):

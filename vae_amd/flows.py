@@ -7,9 +7,11 @@ Class names, constructor arguments, parameter / buffer names (state_dict keys) a
 cond_inputs=None, mode='direct')` follow the reference, so a reference checkpoint of a MAF / MAF-split /
 RealNVP flow loads.  `mode='inverse'` (sampling; not on the training hot path) is plain PyTorch.
 
-Not here (stock GEMM / tiny layers of the host project): ActNorm, InvertibleMM, LUInvertibleMM, Shuffle,
-Sigmoid / Logit and the glow builder.  `helpers.layers.BasicDenseBlock` / `str_to_activ_module` are
-un-vendored: the coupling nets default to Linear -> act -> Linear -> act -> Linear and can be injected.
+The glow-side layers are here too, so that every `flow_type` of reparameterizers/flow.py:20-49 builds: ActNorm runs
+its per-column affine map on the BatchNormFlow kernels; InvertibleMM / LUInvertibleMM are one GEMM and a log-determinant
+(stock torch ops), Shuffle an index permutation.  Not here: Sigmoid / Logit.  `helpers.layers.BasicDenseBlock` /
+`str_to_activ_module` are un-vendored: the coupling nets default to Linear -> act -> Linear -> act -> Linear and can be
+injected.
 """
 import math
 
@@ -252,6 +254,97 @@ class AdditiveCouplingLayer(_FlowLayer):
         return inputs - t, torch.zeros_like(t).sum(-1, keepdim=True)
 
 
+class ActNorm(_FlowLayer):
+    """flows/__init__.py:274-299: y = (x - bias) * exp(weight); the first batch seen sets weight = -log(std + 1e-12)
+    and bias = mean per feature.  Same parameter names; `initialized` is plain Python state, as there."""
+
+    def __init__(self, num_inputs):
+        super(ActNorm, self).__init__()
+        self.weight = nn.Parameter(torch.ones(num_inputs))
+        self.bias = nn.Parameter(torch.zeros(num_inputs))
+        self.initialized = False
+
+    def _init_from(self, inputs):
+        with torch.no_grad():
+            self.weight.copy_(torch.log(1.0 / (inputs.std(0) + 1e-12)))
+            self.bias.copy_(inputs.mean(0))
+        self.initialized = True
+
+    def _step(self, inputs, cond_inputs, logdet_acc):
+        if not self.initialized:
+            self._init_from(inputs)
+        return F_.actnorm(inputs, self.weight, self.bias, logdet_in=logdet_acc)
+
+    def _inverse(self, inputs, cond_inputs):
+        if not self.initialized:
+            self._init_from(inputs)
+        total = -self.weight.sum().reshape(1, 1).expand(inputs.size(0), 1)
+        return inputs * torch.exp(-self.weight) + self.bias, total
+
+
+class InvertibleMM(nn.Module):
+    """flows/__init__.py:302-321: y = x @ W, logdet = log|det W| for every row.  One GEMM + one slogdet: stock ops."""
+
+    def __init__(self, num_inputs):
+        super(InvertibleMM, self).__init__()
+        self.W = nn.Parameter(torch.empty(num_inputs, num_inputs))
+        nn.init.orthogonal_(self.W)
+
+    def forward(self, inputs, cond_inputs=None, mode='direct'):
+        logabsdet = torch.slogdet(self.W)[1].reshape(1, 1).expand(inputs.size(0), 1)
+        if mode == 'direct':
+            return inputs @ self.W, logabsdet
+        return inputs @ torch.inverse(self.W), -logabsdet
+
+
+class LUInvertibleMM(nn.Module):
+    """flows/__init__.py:324-369: W = P (L_strict + I) (U_strict + diag(sign_S * exp(log_S))) from a fixed LU
+    factorisation of a random orthogonal matrix; logdet = sum(log_S).  Parameters L, U, log_S as there; P, sign_S and
+    the masks are non-persistent buffers (they follow .to(device) and, as in the reference, are not checkpointed)."""
+
+    def __init__(self, num_inputs):
+        super(LUInvertibleMM, self).__init__()
+        import scipy.linalg
+        w0 = torch.empty(num_inputs, num_inputs)
+        nn.init.orthogonal_(w0)
+        perm, lower, upper = scipy.linalg.lu(w0.numpy())
+        diag = np.diag(upper)
+        strict = torch.tril(torch.ones(num_inputs, num_inputs), -1)
+        self.L = nn.Parameter(torch.from_numpy(lower))
+        self.U = nn.Parameter(torch.from_numpy(upper))
+        self.log_S = nn.Parameter(torch.from_numpy(np.log(np.abs(diag))))
+        self.register_buffer('P', torch.from_numpy(perm), persistent=False)
+        self.register_buffer('sign_S', torch.from_numpy(np.sign(diag)), persistent=False)
+        self.register_buffer('L_mask', strict, persistent=False)
+        self.register_buffer('U_mask', strict.t().clone(), persistent=False)
+        self.register_buffer('eye', torch.eye(num_inputs), persistent=False)
+
+    def matrix(self):
+        lower = self.L * self.L_mask + self.eye
+        upper = self.U * self.U_mask + torch.diag(self.sign_S * torch.exp(self.log_S))
+        return self.P @ lower @ upper
+
+    def forward(self, inputs, cond_inputs=None, mode='direct'):
+        total = self.log_S.sum().reshape(1, 1).expand(inputs.size(0), 1)
+        if mode == 'direct':
+            return inputs @ self.matrix(), total
+        return inputs @ torch.inverse(self.matrix()), -total
+
+
+class Shuffle(nn.Module):
+    """flows/__init__.py:372-389: a fixed random permutation of the features (numpy's generator, as there)."""
+
+    def __init__(self, num_inputs):
+        super(Shuffle, self).__init__()
+        perm = np.random.permutation(num_inputs)
+        self.register_buffer('perm', torch.from_numpy(perm).long(), persistent=False)
+        self.register_buffer('inv_perm', torch.from_numpy(np.argsort(perm)).long(), persistent=False)
+
+    def forward(self, inputs, cond_inputs=None, mode='direct'):
+        index = self.perm if mode == 'direct' else self.inv_perm
+        return inputs[:, index], torch.zeros(inputs.size(0), 1, device=inputs.device, dtype=inputs.dtype)
+
+
 class FlowSequential(nn.Sequential):
     """flows/__init__.py:536-579.  'direct': every kernel-backed layer adds its logdet to the running [B]
     total inside its own launch; BatchNormFlow followed by Reverse is one launch."""
@@ -279,7 +372,7 @@ class FlowSequential(nn.Sequential):
                 inputs, acc = module._step(inputs, cond_inputs, acc)
             else:
                 inputs, logdet = module(inputs, cond_inputs, mode)
-                if not (isinstance(module, Reverse)):            # a permutation adds nothing
+                if not isinstance(module, (Reverse, Shuffle)):    # a permutation adds nothing
                     acc = logdet.reshape(-1).expand(inputs.size(0)) if acc is None else acc + logdet.reshape(-1)
             i += 1
         if acc is None:
@@ -330,5 +423,30 @@ def build_realnvp_flow(num_inputs, num_hidden, num_cond_inputs=None, num_blocks=
         modules += [CouplingLayer(num_inputs, num_hidden, mask, num_cond_inputs, s_act=s_activation_str,
                                   t_act=t_activation_str, normalization_str=normalization_str),
                     BatchNormFlow(num_inputs)]
+        mask = 1 - mask
+    return FlowSequential(*modules)
+
+
+def build_maf_split_glow_flow(num_inputs, num_hidden, num_cond_inputs=None, num_blocks=5, s_activation_str='tanh',
+                              t_activation_str='relu'):
+    """flows/__init__.py:612-625: MADESplit -> BatchNormFlow -> InvertibleMM per block."""
+    modules = []
+    for _ in range(num_blocks):
+        modules += [MADESplit(num_inputs, num_hidden, num_cond_inputs, s_act=s_activation_str, t_act=t_activation_str),
+                    BatchNormFlow(num_inputs), InvertibleMM(num_inputs)]
+    return FlowSequential(*modules)
+
+
+def build_glow_flow(num_inputs, num_hidden, num_cond_inputs=None, num_blocks=5, activation_str='relu',
+                    normalization_str='batchnorm', layer_modifier='none', cuda=True):
+    """flows/__init__.py:651-673: ActNorm -> InvertibleMM -> AdditiveCouplingLayer per block, alternating masks."""
+    modules = []
+    device = torch.device('cuda' if cuda else 'cpu')
+    mask = (torch.arange(0, num_inputs) % 2).to(device).float()
+    for _ in range(num_blocks):
+        modules += [ActNorm(num_inputs), InvertibleMM(num_inputs),
+                    AdditiveCouplingLayer(num_inputs, num_hidden, mask, act=activation_str,
+                                          num_cond_inputs=num_cond_inputs, normalization_str=normalization_str,
+                                          layer_modifier=layer_modifier)]
         mask = 1 - mask
     return FlowSequential(*modules)

@@ -1260,6 +1260,60 @@ class _BNFlow(torch.autograd.Function):
         return gx, g_lg, g_beta, None, None, (gld if has_ld else None), None, None, None, None, None
 
 
+class _ActNorm(torch.autograd.Function):
+    """ActNorm 'direct' (flows/__init__.py:292-295): y = (x - bias) * exp(weight), logdet += sum(weight).  The same
+    per-column affine map as BatchNormFlow in eval mode with mean = bias, var = 1, log_gamma = weight, beta = 0, so it
+    runs on those kernels (csrc/flowtail.hip); the backward's column sums give the parameter gradients:
+    d bias = -exp(weight) * sum_b gy,  d weight = exp(weight) * sum_b gy * (x - bias) + sum_b glogdet."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, logdet_in):
+        ctx.set_materialize_grads(False)
+        dev = check_device(x, weight, bias, logdet_in)
+        B, F = x.shape
+        y = torch.empty_like(x)
+        ld = torch.empty((B,), dtype=x.dtype, device=dev)
+        stats = torch.empty((_lib.load().vae_bnflow_stats_floats(F),), dtype=torch.float32, device=dev)
+        w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        zeros, ones = torch.zeros_like(w32), torch.ones_like(w32)
+        with _Guard(dev):
+            call('vae_bnflow_fwd', ptr(x), ptr(w32), ptr(zeros), ptr(b32), ptr(ones), ptr(stats), ptr(y),
+                 ptr(logdet_in), ptr(ld), B, F, 0.0, 0, 0, dtype_code(x), stream_ptr(dev))
+        ctx.save_for_backward(x, w32, stats)
+        ctx.cfg = (logdet_in is not None, weight.dtype)
+        return y, ld
+
+    @staticmethod
+    def backward(ctx, gy, gld):
+        x, w32, stats = ctx.saved_tensors
+        has_ld, pdt = ctx.cfg
+        dev = x.device
+        B, F = x.shape
+        gld = _dense(gld)
+        gy = torch.zeros_like(x) if gy is None else gy.contiguous()
+        gx = torch.empty_like(x)
+        with _Guard(dev):
+            call('vae_bnflow_bwd', ptr(x), ptr(gy), ptr(gld), ptr(stats), ptr(gx), B, F, 0, 0, dtype_code(x),
+                 stream_ptr(dev))
+        sums = stats[6 * F:8 * F + 1]
+        scale = torch.exp(w32)
+        g_weight = (scale * sums[F:2 * F] + sums[2 * F]).to(pdt)
+        g_bias = (-scale * sums[:F]).to(pdt)
+        return gx, g_weight, g_bias, (gld if has_ld else None)
+
+
+def actnorm(x, weight, bias, logdet_in=None):
+    """-> (y [B, F], logdet_out [B]) of an ActNorm layer with the given parameters (no data-dependent init here)."""
+    x = x.contiguous()
+    F = x.shape[1]
+    if weight.numel() != F or bias.numel() != F:
+        raise ValueError("actnorm: the parameter vectors must have x.shape[1] = %d entries" % F)
+    ld = None if logdet_in is None else logdet_in.reshape(-1).contiguous()
+    if x.shape[0] == 0:
+        return torch.empty_like(x), x.new_empty((0,))
+    return _ActNorm.apply(x, weight, bias, ld)
+
+
 def bnflow(x, log_gamma, beta, running_mean=None, running_var=None, logdet_in=None, eps=1e-5, training=True,
            reverse=False, reduce_fn=None, count=None):
     """BatchNormFlow 'direct' (flows/__init__.py:233-257), optionally with the Reverse that follows it in a

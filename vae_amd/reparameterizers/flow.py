@@ -9,11 +9,10 @@ from .. import functional as F_
 
 class FlowReparameterizer(nn.Module):
     """A fully flow based reparameterizer, built from the reference's own config keys (flow.py:20-49):
-    config['flow_type'] in {'maf', 'maf_split', 'realnvp'} with config['continuous_size'] features,
-    config['latent_size'] hidden units and 5 blocks, through vae_amd.flows' builders (same layer classes, ctor
-    arguments and state_dict keys as flows/__init__.py, so the reference's checkpoints load; the elementwise tails
-    run in csrc/flowtail.hip).  The two glow variants need ActNorm / InvertibleMM / LUInvertibleMM layers, which stay
-    the host project's stock PyTorch: NotImplementedError names them.
+    config['flow_type'] in {'maf', 'maf_split', 'maf_split_glow', 'glow', 'realnvp'} with config['continuous_size']
+    features, config['latent_size'] hidden units and 5 blocks, through vae_amd.flows' builders (same layer classes,
+    ctor arguments and state_dict keys as flows/__init__.py, so the reference's checkpoints load; the elementwise
+    tails run in csrc/flowtail.hip, the invertible 1x1 matrices of the glow variants are stock GEMMs).
 
     Overrides (not in the reference): config['flow_module'] -- an nn.Module whose forward(x[N,F]) returns
     (u[N,F], logdet[N,1]) and that has `.sample(num_samples, noise)` -- or config['flow_builder'],
@@ -43,11 +42,17 @@ class FlowReparameterizer(nn.Module):
                                                      t_activation_str='relu',
                                                      normalization_str=config.get('dense_normalization', 'none'),
                                                      cuda=config.get('cuda', True))
-            elif flow_type in ('glow', 'maf_split_glow'):
-                raise NotImplementedError(
-                    "flow_type '%s' is built from ActNorm / InvertibleMM / LUInvertibleMM layers (flows/__init__.py:"
-                    "260-400), stock PyTorch modules of the host project: pass the built flow as "
-                    "config['flow_module'] (or config['flow_builder'])" % flow_type)
+            elif flow_type == 'maf_split_glow':
+                self.flow = flows.build_maf_split_glow_flow(num_inputs=continuous_size, num_hidden=latent_size,
+                                                            num_cond_inputs=None, num_blocks=5,
+                                                            s_activation_str='tanh', t_activation_str='relu')
+            elif flow_type == 'glow':
+                self.flow = flows.build_glow_flow(num_inputs=continuous_size, num_hidden=latent_size,
+                                                  num_cond_inputs=None, num_blocks=5,
+                                                  activation_str=config.get('encoder_activation', 'relu'),
+                                                  normalization_str=config.get('dense_normalization', 'none'),
+                                                  layer_modifier=config.get('encoder_layer_modifier', 'none'),
+                                                  cuda=config.get('cuda', True))
             else:
                 raise ValueError("unknown flow_type '%s'" % (flow_type,))
         self.input_size = continuous_size
