@@ -166,6 +166,9 @@ def main():
     names = ['gauss_reparam_kl_fwd', 'nll_elbo_fused', 'nll_fused_backward', 'gauss_reparam_kl_bwd'] if fused else \
         ['gauss_reparam_kl_fwd', 'nll_elbo_fwd', 'nll_elbo_bwd', 'gauss_reparam_kl_bwd']
     pmeans = ctypes_off(scalars, 6)
+    T = {'logits': logits, 'noise': noise, 'x': x, 'recon': recon, 'gz': gz, 'z': z, 'kl': kl, 'nll': nll, 'loss': loss,
+         'elbo': elbo, 'scalars': scalars, 'gmeans': gmeans, 'grecon': grecon, 'gkld': gkld, 'glogits': glogits,
+         'pmeans': pmeans, 'dt': 0}        # what step() runs on: swapped for the 16-bit variant below
 
     overlap = dist is not None and backend == 'nccl' and os.environ.get('BENCH_SYNC_ALLREDUCE', '0') != '1'
     pending = [None]
@@ -182,34 +185,34 @@ def main():
             call('vae_rng_next', ptr(rng_cell[0]), 1, st)
             off = (1 << 63) | rng_cell[0].data_ptr()          # VAE_OFFSET_ON_DEVICE
         mark(0)
-        call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, noise_arg[0], ptr(z), L, plogvar, ptr(kl), pmeans,
-             ptr(ws), B, L, 1e-6, mean_scale, 1, 1234, off, row0, 0, st)
+        call('vae_gauss_reparam_kl_fwd', ptr(T['logits']), 2 * L, noise_arg[0], ptr(T['z']), L, plogvar, ptr(T['kl']), T['pmeans'],
+             ptr(ws), B, L, 1e-6, mean_scale, 1, 1234, off, row0, T['dt'], st)
         mark(1)
         if fused:
-            call('vae_nll_elbo_fused', ptr(x), ptr(recon), 0, ptr(kl), None, None, 1.0, inv_count, 1.0, ptr(nll),
-                 ptr(loss), ptr(elbo), ptr(scalars), ptr(ws), ptr(grecon), B, D, 0, st)
+            call('vae_nll_elbo_fused', ptr(T['x']), ptr(T['recon']), 0, ptr(T['kl']), None, None, 1.0, inv_count, 1.0, ptr(T['nll']),
+                 ptr(T['loss']), ptr(T['elbo']), ptr(T['scalars']), ptr(ws), ptr(T['grecon']), B, D, T['dt'], st)
         else:
-            call('vae_nll_elbo_fwd', ptr(x), ptr(recon), 0, ptr(kl), None, None, 1.0, inv_count, ptr(nll), ptr(loss),
-                 ptr(elbo), ptr(scalars), ptr(ws), B, D, 0, st)
+            call('vae_nll_elbo_fwd', ptr(T['x']), ptr(T['recon']), 0, ptr(T['kl']), None, None, 1.0, inv_count, ptr(T['nll']), ptr(T['loss']),
+                 ptr(T['elbo']), ptr(T['scalars']), ptr(ws), B, D, T['dt'], st)
         mark(2)
         if dist is not None:
             # global-batch means (abstract_vae.py:381-387) in one 8-float message.  Nothing later in the step reads
             # them (the kernels pre-scale by 1/B_global), so over RCCL the collective runs on its own stream beside
             # the backward kernels and is joined at the end of the step.
             if overlap:
-                pending[0] = dist.all_reduce(scalars, op=dist.ReduceOp.SUM, async_op=True)
+                pending[0] = dist.all_reduce(T['scalars'], op=dist.ReduceOp.SUM, async_op=True)
             else:
-                all_reduce(scalars)
+                all_reduce(T['scalars'])
         mark(3)
         if fused:
-            call('vae_nll_fused_backward', ptr(grecon), B * D, ptr(gmeans), 1.0, inv_count, ptr(gkld), None, None, B,
-                 0, st)
+            call('vae_nll_fused_backward', ptr(T['grecon']), B * D, ptr(T['gmeans']), 1.0, inv_count, ptr(T['gkld']), None, None, B,
+                 T['dt'], st)
         else:
-            call('vae_nll_elbo_bwd', ptr(x), ptr(recon), 0, None, None, None, ptr(gmeans), 1.0, inv_count,
-                 ptr(grecon), ptr(gkld), None, None, B, D, 0, st)
+            call('vae_nll_elbo_bwd', ptr(T['x']), ptr(T['recon']), 0, None, None, None, ptr(T['gmeans']), 1.0, inv_count,
+                 ptr(T['grecon']), ptr(T['gkld']), None, None, B, D, T['dt'], st)
         mark(4)
-        call('vae_gauss_reparam_kl_bwd', ptr(logits), 2 * L, noise_arg[0], ptr(gz), L, None, ptr(gkld), None,
-             ptr(glogits), 2 * L, B, L, 1e-6, mean_scale, 1, 1234, off, row0, 0, st)
+        call('vae_gauss_reparam_kl_bwd', ptr(T['logits']), 2 * L, noise_arg[0], ptr(T['gz']), L, None, ptr(T['gkld']), None,
+             ptr(T['glogits']), 2 * L, B, L, 1e-6, mean_scale, 1, 1234, off, row0, T['dt'], st)
         mark(5)
         if pending[0] is not None:
             pending[0].wait()                 # the launch stream waits for the collective; no host block
@@ -299,6 +302,40 @@ def main():
             ms = statistics.median(e[a].elapsed_time(e[b]) for e in t2e)
             philox_variant['kernels'][n] = {'avg_ms': round(ms, 5), 'algorithmic_bytes': ab2[n],
                                             'frac': round(ab2[n] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # the same step on bf16 tensors (north_star's second element type; arithmetic stays fp32 inside the kernels):
+    # reported beside the figure, never as `value` (BASELINE.json's metric is the fp32 step)
+    bf16_variant = None
+    if world == 1 and not philox and not args.main_only and not args.materialize_logvar:
+        keep = dict(T)
+        for k in ('logits', 'noise', 'x', 'recon', 'gz'):
+            T[k] = keep[k].to(torch.bfloat16)
+        for k in ('z', 'kl', 'nll', 'loss', 'elbo', 'grecon', 'gkld', 'glogits'):
+            T[k] = torch.empty_like(keep[k], dtype=torch.bfloat16)
+        T['dt'] = 1                                  # VAE_BF16
+        noise_arg[0] = ptr(T['noise'])
+        for _ in range(args.warmup):
+            step()
+        ev3 = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
+        for k in range(args.steps):
+            step(ev3[k])
+        torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+        for k in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        dt4 = time.perf_counter() - t3
+        bf16_variant = {'value': B * args.steps / dt4, 'unit': 'samples/s', 'ms_per_step': dt4 / args.steps * 1e3,
+                        'loss_mean': float(T['scalars'][0].item()), 'kernels': {}}
+        for n, (a, b) in seg.items():
+            ms = statistics.median(e[a].elapsed_time(e[b]) for e in ev3)
+            nbytes = algorithmic_bytes(B)[n] // 2
+            bf16_variant['kernels'][n] = {'avg_ms': round(ms, 5), 'algorithmic_bytes': nbytes,
+                                          'frac': round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        T.clear()
+        T.update(keep)
+        noise_arg[0] = ptr(noise)
+        del keep
 
     # the same launches recorded once into a HIP graph and replayed: what the launch gaps between the four kernels
     # cost.  Once with the injected noise, once with in-kernel Philox draws whose call offset lives in a device word
@@ -423,6 +460,7 @@ def main():
             'whole_model': whole_model,
             'module_path': module_path,
             'philox_variant': philox_variant,
+            'bf16_variant': bf16_variant,
             'stock_torch_same_gpu': stock_torch,
             'graph_replay': graph_replay,
         }
