@@ -80,6 +80,68 @@ __global__ __launch_bounds__(256) void row_kernel(const f4* __restrict__ r0, con
   }
 }
 
+// short rows (16-bit tensors: 784 px = 98 vectors): G lanes per row, RW rows per lane group in flight, UU chunks per row
+template <int G, int RW, int UU, bool NTS>
+__global__ __launch_bounds__(256) void short_row_kernel(const f4* __restrict__ r0, const f4* __restrict__ r1,
+                                                        f4* __restrict__ w0, size_t rows, int rvec) {
+  constexpr int RPB = 256 / G;
+  const int sub = threadIdx.x % G, rloc = threadIdx.x / G;
+  f4 a[RW][UU], b[RW][UU];
+#pragma unroll
+  for (int q = 0; q < RW; ++q) {
+    size_t row = ((size_t)blockIdx.x * RW + q) * RPB + rloc;
+    row = row < rows ? row : rows - 1;
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+      int j = sub + u * G;
+      j = j < rvec ? j : rvec - 1;
+      a[q][u] = ld<true>(r0 + row * rvec + j);
+      b[q][u] = ld<true>(r1 + row * rvec + j);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < RW; ++q) {
+    const size_t row = ((size_t)blockIdx.x * RW + q) * RPB + rloc;
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+      const int j = sub + u * G;
+      if (row < rows && j < rvec) st<NTS>(w0 + row * rvec + j, a[q][u] * 1.0001f + b[q][u]);
+    }
+  }
+}
+
+template <int G, int RW, int UU, bool NTS>
+double run_short(const char* name, std::vector<f4*>& pool, size_t nvec, int rvec, int iters) {
+  const int nsets = (int)pool.size() / 3;
+  const size_t rows = nvec / rvec;
+  const size_t per_block = (size_t)(256 / G) * RW;
+  const size_t blocks = (rows + per_block - 1) / per_block;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto launch = [&](int it) {
+    f4** b = &pool[(it % nsets) * 3];
+    hipLaunchKernelGGL((short_row_kernel<G, RW, UU, NTS>), dim3((unsigned)blocks), dim3(256), 0, 0, b[0], b[1], b[2], rows,
+                       rvec);
+  };
+  for (int i = 0; i < 3; ++i) launch(i);
+  std::vector<double> t;
+  for (int rep = 0; rep < 5; ++rep) {
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) launch(i);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    t.push_back(ms / iters);
+  }
+  std::sort(t.begin(), t.end());
+  const double bytes = (double)rows * rvec * 16 * 3;
+  const double tbs = bytes / (t[2] * 1e-3) / 1e12;
+  printf("%-34s 2R1W rows of %d B G%d x%d rows U%d nts%d grid %-7zu  %8.1f us  %5.2f TB/s (%.3f of 8)\n", name, rvec * 16, G,
+         RW, UU, (int)NTS, blocks, t[2] * 1e3, tbs, tbs / 8.0);
+  fflush(stdout);
+  return tbs;
+}
+
 template <int R, int W, bool NTL, bool NTS>
 double run_rows(const char* name, std::vector<f4*>& pool, size_t nvec, int rvec, int iters) {
   const int per = R + W;
@@ -251,6 +313,19 @@ int main(int argc, char** argv) {
   run_rows<2, 1, true, false>("rows 2R1W 800 px", pool, nvec, 200, it);
   run_rows<3, 1, true, false>("rows 3R1W 512", pool, nvec, 128, it);
   run_rows<3, 1, true, true>("rows 3R1W 512 nt stores", pool, nvec, 128, it);
+  if (argc > 3 && argv[3][0] == 's') {   // short rows: mb = 103 for the bf16 C2 streams
+    run_short<64, 1, 2, true>("short G64 1 row U2 (library)", pool, nvec, 98, it);
+    run_short<64, 2, 2, true>("short G64 2 rows U2", pool, nvec, 98, it);
+    run_short<64, 4, 2, true>("short G64 4 rows U2", pool, nvec, 98, it);
+    run_short<32, 1, 4, true>("short G32 1 row U4", pool, nvec, 98, it);
+    run_short<32, 2, 4, true>("short G32 2 rows U4", pool, nvec, 98, it);
+    run_short<16, 1, 7, true>("short G16 1 row U7", pool, nvec, 98, it);
+    run_short<16, 2, 7, true>("short G16 2 rows U7", pool, nvec, 98, it);
+    run_short<64, 1, 2, false>("short G64 1 row U2 plain st", pool, nvec, 98, it);
+    run_short<64, 1, 2, true>("short 128-vector rows G64 U2", pool, nvec, 128, it);
+    run_short<64, 2, 2, true>("short 128-vector rows G64 x2", pool, nvec, 128, it);
+    return 0;
+  }
   if (argc > 3) {
     for (int grid : {1024, 2048, 4096}) {
       run_persist<true, 0>("persistent naive", pool, nvec, 196, grid, it);
