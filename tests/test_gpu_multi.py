@@ -297,3 +297,22 @@ def test_nll_multi_more_than_max_samples_16bit(dtype, rtol):
     for a, b in zip(g1, g0):
         assert a.dtype == dtype
         close(a, b, rtol=rtol, atol=rtol * float(b.abs().max()))
+
+
+@pytest.mark.parametrize('dtype,rtol', [(torch.float32, 1e-5), (torch.bfloat16, 2e-2), (torch.float16, 4e-3)])
+@pytest.mark.parametrize('T,B', [(1, 9), (5, 300), (128, 33)])
+def test_steps_logsumexp_epilogue(dtype, rtol, T, B):
+    """with_lse: the closing launch's log-sum-exp over the steps == torch.logsumexp over the per-step elbo column it
+    also returns; +inf / -inf entries behave as torch's (max shift taken out only when finite)."""
+    from vae_amd import functional as F_
+    torch.manual_seed(T + B)
+    D = 40
+    x = (torch.rand(B, D, device=DEV) < 0.4).to(dtype)
+    recons = [(torch.randn(B, D, device=DEV) * 2).to(dtype) for _ in range(T)]
+    kld = (torch.rand(T * B, device=DEV) * 3).to(dtype)
+    out = F_.nll_steps_elbo([x] * T, recons, 'bernoulli', kld=kld, with_lse=True)
+    elbo, lse = out[2], out[6]
+    assert lse.shape == (B,) and lse.dtype == dtype and not lse.requires_grad
+    want = torch.logsumexp(elbo.float().view(T, B), 0)
+    close(lse, want, rtol=rtol, atol=rtol)
+    assert len(F_.nll_steps_elbo([x] * T, recons, 'bernoulli', kld=kld)) == 6
