@@ -483,7 +483,9 @@ def whole_model_leg(dev, x_img, B, world, fence, all_reduce_max, steps=10, warmu
     model = SimpleVAE(config).to(dev).train()
     if world > 1:
         vdist.configure(model, B * world)
-    flat = vdist.FlatGradients(model.parameters())
+    # BENCH_GRAD_BUCKETS=n: n pieces, each sent as soon as backward has filled it (default: one message after backward;
+    # 6.4 MB is latency-bound on xGMI either way)
+    flat = vdist.FlatGradients(model.parameters(), buckets=int(os.environ.get('BENCH_GRAD_BUCKETS', '1')))
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
 
     def wstep():

@@ -51,6 +51,8 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--batch', type=int, default=4096, help='rows per GPU')
     ap.add_argument('--latent', type=int, default=64)
+    ap.add_argument('--buckets', type=int, default=1,
+                    help='cut the flat gradient buffer into this many pieces, each all-reduced as soon as backward has filled it')
     ap.add_argument('--ddp', action='store_true', help="torch DDP instead of vae_amd.dist.FlatGradients (RCCL only)")
     args = ap.parse_args()
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
@@ -75,7 +77,7 @@ def main():
         vdist.configure(model, args.batch * world)
     if ddp:
         net = nn.parallel.DistributedDataParallel(model, device_ids=[dev.index])
-    flat = None if ddp else vdist.FlatGradients(model.parameters())
+    flat = None if ddp else vdist.FlatGradients(model.parameters(), buckets=args.buckets)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
     proto = (torch.rand(16, 1, 28, 28, generator=gen, device=dev) < 0.15).float()      # 16 "digit" prototypes

@@ -115,7 +115,7 @@ def test_single_process_is_identity():
     assert x is a and y is b
 
 
-def _grad_worker(rank, world, port, outdir):
+def _grad_worker(rank, world, port, outdir, buckets=1):
     """A tiny encoder -> (oracle) Gaussian latent + Bernoulli loss -> decoder model on this rank's rows: the flat
     gradient buffer summed over ranks must be the single-process gradient of the global batch."""
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -129,7 +129,8 @@ def _grad_worker(rank, world, port, outdir):
     noise = torch.randn(Bg, L)
     row0, rows = VD.shard_rows(Bg)
     sl = slice(row0, row0 + rows)
-    flat = VD.FlatGradients(list(enc.parameters()) + list(dec.parameters()))
+    flat = VD.FlatGradients(list(enc.parameters()) + list(dec.parameters()), buckets=buckets)
+    assert len(flat._pieces) == 1 if buckets == 1 else 1 < len(flat._pieces) <= buckets
     for _ in range(2):              # twice: the second pass must not see the first pass's sums
         flat.zero()
         z, params = O.gauss_forward(enc(x[sl]), noise[sl])
@@ -143,10 +144,16 @@ def _grad_worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_flat_gradients_two_ranks_equal_one_rank(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize('buckets', [1, 2, 4])
+def test_flat_gradients_two_ranks_equal_one_rank(tmp_path, buckets):
+    """buckets > 1: the pieces are all-reduced asynchronously from post-accumulate-grad hooks while the backward pass
+    is still running (the decoder's piece first); same sums."""
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
-    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, str(tmp_path), buckets)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -89,34 +89,104 @@ class FlatGradients(object):
 
         flat = FlatGradients(model.parameters())
         ... flat.zero(); loss.backward(); flat.all_reduce(); optimizer.step()      # never zero_grad(set_to_none=True)
-    """
 
-    def __init__(self, params):
+    `buckets` > 1 (larger networks): the buffer is cut into that many contiguous pieces of about equal size and a
+    piece is all-reduced, asynchronously on the collective's own stream, as soon as the backward pass has accumulated
+    the gradient of its last parameter (post-accumulate-grad hooks) -- the pieces holding the decoder's parameters
+    cross xGMI while the encoder's backward still runs; all_reduce() then only launches what is left and waits.
+    One backward() per zero() / all_reduce() pair (no gradient accumulation over several backward passes).  Under a
+    gloo group with device tensors the pieces are reduced at all_reduce() (host-staged, synchronous)."""
+
+    def __init__(self, params, buckets=1):
         self.params = [p for p in params if p.requires_grad]
         assert self.params, "no parameters that require a gradient"
         p0 = self.params[0]
         sizes = [p.numel() for p in self.params]
-        self.flat = torch.zeros(sum(sizes), dtype=p0.dtype, device=p0.device)
+        total = sum(sizes)
+        self.flat = torch.zeros(total, dtype=p0.dtype, device=p0.device)
         o = 0
+        starts = []
         for p, n in zip(self.params, sizes):
             assert p.dtype == p0.dtype and p.device == p0.device, "one dtype and device per FlatGradients"
             p.grad = self.flat[o:o + n].view_as(p)
+            starts.append(o)
             o += n
+        # contiguous pieces of about total / buckets elements, cut at parameter boundaries
+        buckets = max(1, min(int(buckets), len(self.params)))
+        self._pieces = []          # (first element, end element, number of parameters)
+        first, count, target = 0, 0, total / buckets
+        for k, (st, n) in enumerate(zip(starts, sizes)):
+            count += 1
+            last = k == len(sizes) - 1
+            if last or (st + n - first >= target and len(self._pieces) < buckets - 1):
+                self._pieces.append((first, st + n, count))
+                first, count = st + n, 0
+        self._owner = {}
+        self._pending = [c for _, _, c in self._pieces]
+        self._work = [None] * len(self._pieces)
+        self._launched = [False] * len(self._pieces)
+        self._group = None
+        if len(self._pieces) > 1:
+            k = 0
+            for idx, (p, st) in enumerate(zip(self.params, starts)):
+                while st >= self._pieces[k][1]:
+                    k += 1
+                self._owner[idx] = k
+                p.register_post_accumulate_grad_hook(lambda _p, piece=k: self._accumulated(piece))
 
     @property
     def nbytes(self):
         return self.flat.numel() * self.flat.element_size()
+
+    def _distributed(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1
+
+    def _async_ok(self):
+        # a gloo group reduces device tensors through the host, synchronously (see _sum_over_ranks_): at all_reduce()
+        return not (self.flat.is_cuda and dist.get_backend(self._group) == 'gloo')
+
+    def _launch(self, k):
+        a, b, _ = self._pieces[k]
+        self._launched[k] = True
+        if self._async_ok():
+            self._work[k] = dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self._group, async_op=True)
+        else:
+            _sum_over_ranks_(self.flat[a:b], self._group)
+
+    def _accumulated(self, k):
+        self._pending[k] -= 1
+        if self._pending[k] == 0 and self._distributed() and self._async_ok():
+            self._launch(k)
 
     def zero(self):
         for p in self.params:       # somebody replaced a view (zero_grad(set_to_none=True), a fresh .grad): put it back
             if p.grad is None or p.grad.untyped_storage().data_ptr() != self.flat.untyped_storage().data_ptr():
                 raise RuntimeError("FlatGradients: a parameter's .grad no longer aliases the flat buffer "
                                    "(use flat.zero(), not zero_grad(set_to_none=True))")
+        assert not any(w is not None for w in self._work), "FlatGradients: zero() before all_reduce() finished the step"
         self.flat.zero_()
+        self._pending = [c for _, _, c in self._pieces]
+        self._launched = [False] * len(self._pieces)
 
     def all_reduce(self, group=None):
-        """Sum over ranks, in place; identity when not distributed."""
-        return all_reduce_inplace(self.flat, group)
+        """Sum over ranks, in place; identity when not distributed.  With buckets: launches the pieces the backward
+        pass has not already sent and waits for all of them (the current stream waits; the host does not block under
+        RCCL)."""
+        if len(self._pieces) == 1:
+            return all_reduce_inplace(self.flat, group)
+        assert group is self._group or group is None, "bucketed FlatGradients: pass the group to set_group() first"
+        if self._distributed():
+            for k in range(len(self._pieces)):
+                if not self._launched[k]:
+                    self._launch(k)
+            for k, w in enumerate(self._work):
+                if w is not None:
+                    w.wait()
+                    self._work[k] = None
+        return self.flat
+
+    def set_group(self, group):
+        self._group = group
 
 
 def configure(module, global_batch, rank=None, world_size=None, group=None):
