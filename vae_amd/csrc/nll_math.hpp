@@ -249,7 +249,8 @@ inline void launch_rows_means(const void* loss, const void* elbo, const void* nl
                    (!add || aligned16(add)) && (!mi || aligned16(mi));
   const int64_t items = vec ? (B + VN - 1) / VN : B;
   int64_t blocks = (items + kBlock - 1) / kBlock;
-  const int grid = (int)(blocks < 64 ? blocks : 64);
+  // small batches: ONE block (<= 8 vectors per thread and array) closes without the cross-block ticket chain
+  const int grid = items <= 8 * kBlock ? 1 : (int)(blocks < 64 ? blocks : 64);
   if (vec)
     hipLaunchKernelGGL((elbo_rows_means_kernel<T, VN>), dim3(grid), dim3(kBlock), 0, stream, (const T*)loss, (const T*)elbo,
                        (const T*)nll, (const T*)kld, (const T*)add, (const T*)mi, ws, inv_count, means, B, steps,
