@@ -274,6 +274,47 @@ def nll_steps(Tn, B, D):
                                                    ptr(gmeans), 1.0, inv, ptr(gkld), B, D, 0, st), Tn * B * (12 * D + 4))
 
 
+def vrnn_sequence(Tn, B, L, D=784):
+    """BASELINE config 5 end to end on the hot path: Tn fused posterior/prior steps (vae_amd.vrnn.reparameterize), the
+    loss over all steps in one launch pair, and the whole backward -- eager and replayed from one HIP graph.  The
+    recurrence (LSTM, feature nets, decoder) is the host project's and is not here: its outputs are given tensors."""
+    from vae_amd import vrnn as V
+    from vae_amd.reparameterizers import IsotropicGaussian
+    cfg = {'reparam_type': 'isotropic_gaussian', 'continuous_size': 2 * L, 'nll_type': 'bernoulli', 'kl_beta': 1.0,
+           'use_prior_kl': True, 'cuda': True, 'half': False}
+    rep = IsotropicGaussian(cfg).train()
+    enc = [T(B, 2 * L).requires_grad_(True) for _ in range(Tn)]
+    pri = [T(B, 2 * L).requires_grad_(True) for _ in range(Tn)]
+    xs = [(T(B, 1, 28, 28, kind='rand') < 0.3).float() for _ in range(Tn)]
+    recons = [T(B, 1, 28, 28).requires_grad_(True) for _ in range(Tn)]
+    w = T(B, L)
+
+    def fn():
+        params, zsum = [], 0.0
+        for t in range(Tn):
+            z, p = V.reparameterize(rep, {'encoder_logits': enc[t], 'prior_logits': pri[t], 'x_features': None}, cfg)
+            params.append(p)
+            zsum = zsum + (z['posterior'] * w).sum()
+        out = V.loss_function(rep, cfg, recons, xs, params)
+        torch.autograd.backward([out['loss_mean'] + zsum * (1.0 / (Tn * B))], inputs=enc + pri + recons)
+        for t in enc + pri + recons:
+            t.grad = None
+    # pair fwd 40L+4 and bwd 48L+8 per step and sample; loss fwd 8D+16, bwd 12D
+    nbytes = Tn * B * ((40 * L + 4) + (48 * L + 8) + (8 * D + 16) + 12 * D)
+    cfgs = 'T=%d B=%d L=%d %dpx bernoulli f32: %d pair steps + loss over all steps + backward' % (Tn, B, L, D, Tn)
+    timeit('vrnn sequence (eager)', cfgs, fn, nbytes)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fn()
+    timeit('vrnn sequence (HIP graph)', cfgs, graph.replay, nbytes)
+
+
 def bernoulli(B, K):
     logits, U, gy = T(B, K), T(B, K, kind='rand'), T(B, K)
     y, zh, gl, kl, gkl = T(B, K, kind='e'), T(B, K, kind='e'), T(B, K, kind='e'), T(B, kind='e'), T(B)
@@ -419,6 +460,7 @@ if __name__ == '__main__':
     pair_fused(4096, 32)
     nll(64 * 1024, 784, 0, 'bernoulli T=64 x B=1024')
     nll_steps(64, 1024, 784)
+    vrnn_sequence(64, 1024, 128)
     print('== multi-sample forms (loss_function K > 1, MSGVAE, likelihood)')
     multi(65536, 512, 784, 4)
     multi(16384, 128, 784, 8)
