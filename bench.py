@@ -410,6 +410,8 @@ def main():
 
     if rank == 0:
         ab = algorithmic_bytes(B, philox)
+        if args.materialize_logvar:
+            ab['gauss_reparam_kl_fwd'] += 4 * L * B        # the logvar tensor is written too
         kernels = {}
         for n in names:
             gbs = ab[n] / (dur_ms[n] * 1e-3) / 1e9
