@@ -1,0 +1,59 @@
+"""Run-to-run determinism of the batch scalars: every grid-wide sum is taken in a fixed order (block partials added in
+block order by whichever block arrives last; the closing launch of the NLL kernels likewise), no float atomics
+anywhere -- so repeated launches on the same inputs give the same bits, whatever the arrival order of the blocks."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+REPEATS = 25
+
+
+def _same(run):
+    first = [t.clone() for t in run()]
+    for _ in range(REPEATS - 1):
+        again = run()
+        for a, b in zip(first, again):
+            assert torch.equal(a, b)
+    return first
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gauss_and_nll_means_are_bit_stable(dtype):
+    from vae_amd import functional as F_
+    torch.manual_seed(0)
+    B, L, D = 40000, 96, 300          # > 1024 row tiles: persistent blocks + the ticket chain; ragged rows
+    logits = torch.randn(B, 2 * L, device=DEV).to(dtype)
+    noise = torch.randn(B, L, device=DEV).to(dtype)
+    x = (torch.rand(B, D, device=DEV) < 0.3).to(dtype)
+    recon = torch.randn(B, D, device=DEV).to(dtype)
+    add, mi = torch.rand(B, device=DEV).to(dtype), torch.rand(B, device=DEV).to(dtype)
+
+    def run():
+        z, _, kl, gmeans = F_.gauss_reparam_kl(logits, noise=noise, want_logvar=False)
+        nll, loss, elbo, means = F_.nll_elbo(x, recon, 'bernoulli', kld=kl, add=add, mi=mi, kl_beta=0.7)
+        r2 = recon.clone().requires_grad_(True)
+        _, _, _, fmeans = F_.nll_elbo(x, r2, 'bernoulli', kld=kl, fuse_backward=True)
+        return z, kl, gmeans, nll, loss, elbo, means, fmeans
+    out = _same(run)
+    assert bool(torch.isfinite(out[6]).all())
+
+
+def test_pair_multi_flow_beta_means_are_bit_stable():
+    from vae_amd import functional as F_
+    torch.manual_seed(1)
+    B, L = 30000, 64
+    enc, pri = torch.randn(B, 2 * L, device=DEV), torch.randn(B, 2 * L, device=DEV)
+    nq, np_ = torch.randn(B, L, device=DEV), torch.randn(B, L, device=DEV)
+    u, logdet = torch.randn(B, 2 * L, device=DEV), torch.randn(B, 1, device=DEV)
+    ms = torch.randn(3, B, L, device=DEV)
+
+    def run():
+        pair = F_.gauss_pair(enc, pri, nq, np_, training=True, with_prior_kl=True)
+        multi = F_.gauss_reparam_multi(enc, 3, noise=ms)
+        fkl = F_.flow_kl(u, logdet)
+        beta = F_.beta_split_kl(enc)
+        outs = [t for t in pair if torch.is_tensor(t)] + [t for t in multi if torch.is_tensor(t)]
+        outs += [fkl] + [t for t in beta if torch.is_tensor(t)]
+        return outs
+    _same(run)
