@@ -57,3 +57,36 @@ def test_pair_multi_flow_beta_means_are_bit_stable():
         outs += [fkl] + [t for t in beta if torch.is_tensor(t)]
         return outs
     _same(run)
+
+
+def test_two_streams_do_not_share_a_workspace():
+    """The binding keeps one workspace per (device, stream): launches queued on two streams at once (their ticket
+    counters and partials in flight together) give what the same launches give one after the other."""
+    from vae_amd import functional as F_
+    torch.manual_seed(2)
+    B, L, D = 20000, 64, 200
+    ins = []
+    for k in range(2):
+        ins.append((torch.randn(B, 2 * L, device=DEV), torch.randn(B, L, device=DEV),
+                    (torch.rand(B, D, device=DEV) < 0.3).float(), torch.randn(B, D, device=DEV)))
+
+    def work(k):
+        logits, noise, x, recon = ins[k]
+        z, _, kl, gm = F_.gauss_reparam_kl(logits, noise=noise, want_logvar=False)
+        nll, loss, elbo, means = F_.nll_elbo(x, recon, 'bernoulli', kld=kl)
+        return gm, means, kl, loss
+    serial = [[t.clone() for t in work(k)] for k in range(2)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+    for _ in range(10):
+        outs = [None, None]
+        for rep in range(3):
+            for k, s in enumerate(streams):
+                with torch.cuda.stream(s):
+                    outs[k] = work(k)
+        torch.cuda.synchronize()
+        for k in range(2):
+            for a, b in zip(outs[k], serial[k]):
+                assert torch.equal(a, b)
