@@ -10,10 +10,10 @@ namespace {
 // device the library runs on has its own), advanced by a one-thread node of the graph itself.
 __device__ unsigned long long g_graph_calls;
 __global__ void rng_next_kernel(unsigned long long* cell, unsigned long long n) {
-  // read past the scalar cache: the previous node that wrote the counter may have run a microsecond ago
-  const unsigned long long c = __hip_atomic_load(&g_graph_calls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // one atomic add (a vector-memory atomic at L2): graphs replaying on two streams of a GPU never hand out the same
+  // offsets, and the read does not go through the scalar cache
+  const unsigned long long c = __hip_atomic_fetch_add(&g_graph_calls, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   *cell = VAE_GRAPH_OFFSET_BASE + c + 1ull;
-  g_graph_calls = c + n;
 }
 __global__ void rng_reset_kernel() { g_graph_calls = 0ull; }
 }  // namespace
