@@ -328,7 +328,11 @@ int vae_nll_multi_elbo_bwd(const void* x, const void* const* recons, void* const
  * The T reconstructions and targets stay where the decoder and the data loader left them: xs / recons are HOST
  * arrays of `steps` device pointers (1 <= steps <= VAE_MAX_STEPS), each a contiguous [B, D] / [B, D | 2D] tensor
  * (a pointer may repeat: one target scored at every step), scored as one [steps * B] batch, step-major:
- *   kld [steps*B] (the per-step KL vectors, one after the other) or NULL;
+ *   kld, add, mi [steps*B] (the per-step KL / additional-loss / mutual-information vectors, one after the other:
+ *   abstract_vae.py:356-377 runs per step, so VRNN.mut_info :751-765 and the extra terms are per step too), each
+ *   may be NULL (= 0);  kl_betas: HOST array of `steps` floats, the KL weight of each step (the reference calls
+ *   compute_kl_beta once per step, abstract_vae.py:363: a stateful annealer gives every step its own value), or
+ *   NULL = `kl_beta` at every step;
  *   nll, loss, elbo [steps*B]: the per-step vectors;  loss_avg, elbo_avg [B]: their mean over the steps, summed
  *   step by step in the tensor dtype as the reference does (both NULL: not wanted);  means: 6 floats = sums *
  *   inv_count (inv_count = 1 / (steps * B_global): the mean over steps of the per-step means);
@@ -336,16 +340,18 @@ int vae_nll_multi_elbo_bwd(const void* x, const void* const* recons, void* const
  *   estimate (abstract_vae.py:301-315) when the steps are `steps` decoded draws of each sample's posterior.
  * No counterpart launch structure in the reference: ~40 launches per step there.                              */
 int vae_nll_steps_elbo_fwd(const void* const* xs, const void* const* recons, int64_t steps, int nll_type,
-                           const void* kld, float kl_beta, float inv_count, void* nll, void* loss, void* elbo,
-                           void* loss_avg, void* elbo_avg, void* elbo_lse, float* means, float* workspace, int64_t B,
-                           int64_t D, int dtype, vae_stream_t stream);
+                           const void* kld, const void* add, const void* mi, const float* kl_betas, float kl_beta,
+                           float inv_count, void* nll, void* loss, void* elbo, void* loss_avg, void* elbo_avg,
+                           void* elbo_lse, float* means, float* workspace, int64_t B, int64_t D, int dtype,
+                           vae_stream_t stream);
 /* grecons: HOST array of `steps` device pointers, each written with d / d recons[t] (a reconstruction that is
  * scored at several steps must be given distinct gradient buffers: the caller adds them up);  gnll, gloss,
- * gelbo [steps*B] (each may be NULL), gmeans 6 floats or NULL;  gkld [steps*B] or NULL.                       */
+ * gelbo [steps*B] (each may be NULL), gmeans 6 floats or NULL;  kl_betas / kl_beta as in the forward;
+ * gkld, gadd, gmi [steps*B], each may be NULL.                                                              */
 int vae_nll_steps_elbo_bwd(const void* const* xs, const void* const* recons, void* const* grecons, int64_t steps,
                            int nll_type, const void* gnll, const void* gloss, const void* gelbo, const float* gmeans,
-                           float kl_beta, float inv_count, void* gkld, int64_t B, int64_t D, int dtype,
-                           vae_stream_t stream);
+                           const float* kl_betas, float kl_beta, float inv_count, void* gkld, void* gadd, void* gmi,
+                           int64_t B, int64_t D, int dtype, vae_stream_t stream);
 
 /* ---- flow-layer tails (flows/__init__.py; the masked linears / coupling nets stay stock GEMMs) -----
  * Every tail folds FlowSequential's running `logdets += logdet` (flows/__init__.py:555-557):

@@ -346,6 +346,44 @@ def vrnn_loss(step_losses):
     return agg
 
 
+def clamp_mut_info(mut_info, strategy='none', value=None):
+    """abstract_vae.py:473-488."""
+    strategy = strategy.strip().lower()
+    if strategy == 'norm':
+        return mut_info / torch.norm(mut_info, p=2)
+    if strategy == 'clamp':
+        return torch.clamp(mut_info, min=-value, max=value)
+    assert strategy == 'none'
+    return mut_info
+
+
+def vrnn_mut_info(dist_params, scale, strategy='none', value=None):
+    """vrnn.py:751-765 (IsotropicGaussian reparameterizer): zeros unless the weight is > 0, else the clamped
+    mutual-information proxy of the POSTERIOR's parameters."""
+    if scale > 0:
+        return clamp_mut_info(gauss_mutual_info(dist_params['posterior'], scale), strategy, value)
+    return torch.zeros(dist_params['posterior']['gaussian']['mu'].shape[0])
+
+
+def vrnn_loss_function(recons, xs, params, nll_type, kl_betas, use_prior_kl=False, mi_scale=0.0, strategy='none',
+                       value=None, additive=False, nll_fn=None):
+    """vrnn.py:805-829 / additive_vrnn.py:78-104: AbstractVAE.loss_function (abstract_vae.py:332-388) once per step --
+    nll, VRNN.kld, VRNN.mut_info, that step's KL weight (compute_kl_beta is called inside the step: `kl_betas` is
+    the sequence a stateful annealer produced) -- then _add_loss_map / _mean_map.  xs: a list, or one tensor scored
+    at every step (additive: then every step also uses the LAST reconstruction)."""
+    T = len(recons)
+    if not isinstance(xs, list):
+        xs = [xs for _ in range(T)]
+        if additive:
+            recons = [recons[-1] for _ in range(T)]
+    nll_fn = nll_fn or (lambda x_, r_: nll(x_, r_, nll_type))
+    steps = []
+    for r, x_, p, beta in zip(recons, xs, params, kl_betas):
+        steps.append(loss_function(nll_fn(x_, r), vrnn_kld(p, use_prior_kl), kl_beta=beta,
+                                   mut_info=vrnn_mut_info(p, mi_scale, strategy, value)))
+    return vrnn_loss(steps)
+
+
 # --------------------------------------------------------------------------- flow tails
 def made_tail(x, m, a, pre_exp_tanh=False):
     """flows/__init__.py:121-125 (MADESplit) / :176-178 (MADE), 'direct': -> (u, logdet [B,1])."""

@@ -267,11 +267,12 @@ def nll_steps(Tn, B, D):
     px, pr, pg = _lib.ptr_array(xs), _lib.ptr_array(rs), _lib.ptr_array(gs)
     cfg = 'T=%d x B=%d D=%d bernoulli f32, %d tensors each side' % (Tn, B, D, Tn)
     inv = 1.0 / (Tn * B)
-    timeit('nll_steps_elbo_fwd', cfg, lambda: call('vae_nll_steps_elbo_fwd', px, pr, Tn, 0, ptr(kld), 1.0, inv, ptr(nll_),
+    timeit('nll_steps_elbo_fwd', cfg, lambda: call('vae_nll_steps_elbo_fwd', px, pr, Tn, 0, ptr(kld), None, None, None, 1.0, inv, ptr(nll_),
                                                    ptr(loss), ptr(elbo), ptr(la), ptr(ea), None, ptr(means), ptr(ws), B, D,
                                                    0, st), Tn * B * (8 * D + 16))
     timeit('nll_steps_elbo_bwd', cfg, lambda: call('vae_nll_steps_elbo_bwd', px, pr, pg, Tn, 0, None, None, None,
-                                                   ptr(gmeans), 1.0, inv, ptr(gkld), B, D, 0, st), Tn * B * (12 * D + 4))
+                                                   ptr(gmeans), None, 1.0, inv, ptr(gkld), None, None, B, D, 0, st),
+           Tn * B * (12 * D + 4))
 
 
 def vrnn_sequence(Tn, B, L, D=784):

@@ -717,6 +717,79 @@ def make_glow(vae, out):
             'param_names': [k for k, _ in m.named_parameters()]})
 
 
+def make_vrnn_loss(vae, out):
+    """VRNN.loss_function / AdditiveVRNN.loss_function themselves (vrnn.py:805-829, additive_vrnn.py:78-104) on an
+    un-constructed VRNN instance: T = 4 steps of AbstractVAE.loss_function with everything a step can carry switched
+    on -- use_prior_kl, continuous_mut_info > 0 with a clamp that bites (vrnn.py:751-765, abstract_vae.py:473-488) and
+    a STATEFUL kl_annealer (abstract_vae.py:319-330, :363: it advances once per step).  The NLL is the stub's own
+    (Bernoulli via torch.distributions; helpers is absent): the fixture pins the per-step combine and the
+    aggregation, not an NLL definition."""
+    V = sys.modules['models.vae.vrnn'].VRNN
+    AVR = sys.modules['models.vae.additive_vrnn'].AdditiveVRNN
+    R = vae.reparameterizers
+    B, L, T, Dx = 8, 4, 4, 12
+
+    class Anneal(object):
+        def __init__(self):
+            self.calls = 0
+            self.seen = []
+
+        def __call__(self, kl_beta_list):
+            self.calls += 1
+            res = [v * min(1.0, self.calls / 8.0) for v in kl_beta_list]
+            self.seen.append(res[0])
+            return res
+
+    for name, cls in (('vrnn', V), ('additive', AVR)):
+        torch.manual_seed(1600)
+        cfg = base_config(continuous_size=2 * L, reparam_type='isotropic_gaussian', use_prior_kl=True, kl_beta=0.5,
+                          continuous_mut_info=0.7, mut_clamp_strategy='clamp', mut_clamp_value=1.5,
+                          nll_type='bernoulli')
+        rep = R.IsotropicGaussian(cfg)
+        rep.train(True)
+        st = cls.__new__(cls)
+        nn.Module.__init__(st)
+        st.config = cfg
+        st.reparameterizer = rep
+        st.kl_annealer = Anneal()
+        st.nll = lambda x, recon_x, nll_type: -torch.sum(D.Bernoulli(logits=recon_x).log_prob(x), -1)
+        steps, recons, xs, params = [], [], [], []
+        for t in range(T):
+            enc = torch.randn(B, 2 * L)
+            enc = torch.cat([enc[:, :L], enc[:, L:].abs() + 0.5], -1).requires_grad_(True)
+            pri = torch.randn(B, 2 * L, requires_grad=True)
+            xhat = (enc.detach() + 0.4 * torch.randn(B, 2 * L)).requires_grad_(True)   # the re-encoded reconstruction
+            recon = torch.randn(B, Dx, requires_grad=True)
+            x_t = (torch.rand(B, Dx) < 0.3).float()
+            torch.manual_seed(1700 + t)
+            n_post = torch.zeros(B, L).normal_()
+            n_prior = torch.zeros(B, L).normal_()
+            n_xhat = torch.zeros(B, L).normal_()
+            torch.manual_seed(1700 + t)
+            _, p = cls.reparameterize(st, {'encoder_logits': enc, 'prior_logits': pri, 'x_features': None})
+            _, q_xhat = rep(xhat)                                   # vrnn.py:745-746
+            p['posterior']['q_z_given_xhat'] = q_xhat
+            steps.append({'enc_logits': enc, 'prior_logits': pri, 'xhat_logits': xhat, 'noise_post': n_post,
+                          'noise_prior': n_prior, 'noise_xhat': n_xhat, 'recon': recon, 'x': x_t,
+                          'mut_info': cls.mut_info(st, p, B), 'kld': cls.kld(st, p)})
+            recons.append(recon)
+            xs.append(x_t)
+            params.append(p)
+        if name == 'additive':
+            res = cls.loss_function(st, recons, xs[0], params)     # one target: every step scored on the last recon
+        else:
+            res = cls.loss_function(st, recons, xs, params)
+        leaves = [s_[k] for s_ in steps for k in ('enc_logits', 'prior_logits', 'xhat_logits', 'recon')]
+        grads = torch.autograd.grad(res['loss_mean'], leaves, allow_unused=True)
+        for i, s_ in enumerate(steps):
+            for j, k in enumerate(('enc_logits', 'prior_logits', 'xhat_logits', 'recon')):
+                g = grads[4 * i + j]
+                s_['grad_' + k] = None if g is None else g.detach().clone()
+        out['vrnnloss_%s' % name] = detach_tree({
+            'steps': steps, 'result': res, 'kl_betas': list(st.kl_annealer.seen), 'config': dict(cfg),
+            'annealer': 'beta * min(1, calls / 8), calls counted from 1 over the life of the model'})
+
+
 def main():
     vae = install_reference()
     out = {}
@@ -734,6 +807,7 @@ def main():
     make_conditioned(vae, out)
     make_flowtail(vae, out)
     make_glow(vae, out)
+    make_vrnn_loss(vae, out)
     groups = {}
     for k, v in out.items():
         groups.setdefault(k.split('_')[0], {})[k] = v

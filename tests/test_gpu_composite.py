@@ -264,6 +264,180 @@ def test_vrnn_step_logvars_are_produced_on_first_read():
     assert not torch.allclose(k2, rep.kl(params['posterior'], params['prior']))
 
 
+class _Anneal(object):
+    """The stateful annealer of tests/golden/make_golden.py:make_vrnn_loss (advances once per compute_kl_beta call)."""
+
+    def __init__(self):
+        self.calls = 0
+        self.seen = []
+
+    def __call__(self, kl_beta_list):
+        self.calls += 1
+        res = [v * min(1.0, self.calls / 8.0) for v in kl_beta_list]
+        self.seen.append(res[0])
+        return res
+
+
+def _vrnn_host(c, additive=False, own_nll=None):
+    """A host model as INTEGRATION.md wires it: the mixin first, an nn.Module behind it."""
+    from vae_amd import vrnn as V
+    from vae_amd.reparameterizers import IsotropicGaussian
+
+    class Host(V.AdditiveVRNNMixin if additive else V.VRNNMixin, torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.config = c
+            self.reparameterizer = IsotropicGaussian(c)
+            self.kl_annealer = _Anneal()
+
+    if own_nll is not None:
+        Host.nll = own_nll
+    return Host().train()
+
+
+def _golden_vrnn_steps(g, model, leaves_to=None):
+    recons, xs, params, leaves = [], [], [], []
+    for s in g['steps']:
+        enc, pri, xhat, recon = (s[k].to(DEV).requires_grad_(True) for k in ('enc_logits', 'prior_logits',
+                                                                               'xhat_logits', 'recon'))
+        _, p = model.reparameterize({'encoder_logits': enc, 'prior_logits': pri, 'x_features': None},
+                                    noise=(s['noise_post'].to(DEV), s['noise_prior'].to(DEV)))
+        _, q = model.reparameterizer(xhat, noise=s['noise_xhat'].to(DEV))
+        p['posterior']['q_z_given_xhat'] = q                       # vrnn.py:745-746
+        close(model.mut_info(p, enc.shape[0]), s['mut_info'], rtol=1e-5, atol=1e-6)
+        close(model.kld(p), s['kld'], rtol=1e-5, atol=1e-4)
+        leaves += [enc, pri, xhat, recon]
+        recons.append(recon)
+        xs.append(s['x'].to(DEV))
+        params.append(p)
+    return recons, xs, params, leaves
+
+
+@pytest.mark.parametrize('name', ['vrnnloss_vrnn', 'vrnnloss_additive'])
+def test_vrnn_loss_function_golden_with_mut_info_prior_kl_and_annealer(golden, name):
+    """The reference's VRNN.loss_function / AdditiveVRNN.loss_function run by the reference itself (T = 4) with
+    use_prior_kl, continuous_mut_info > 0 under a clamp that bites and a kl_annealer that advances once per step
+    (vrnn.py:751-765,805-829; abstract_vae.py:319-330,360-363,377): the drop-in mixin through the step-table launch."""
+    g = golden('vrnnloss')[name]
+    additive = name.endswith('additive')
+    c = dict(g['config'], cuda=True)
+    model = _vrnn_host(c, additive=additive)
+    recons, xs, params, leaves = _golden_vrnn_steps(g, model)
+    out = model.loss_function(recons, xs[0] if additive else xs, params)
+    ref = g['result']
+    assert set(out) == set(ref) and out['count'] == ref['count']
+    assert model.kl_annealer.seen == pytest.approx(g['kl_betas'], rel=0, abs=0)       # one call per step, in order
+    assert out['kl_beta_scalar'] == pytest.approx(ref['kl_beta_scalar'], rel=1e-12)
+    for k in ('loss', 'elbo', 'loss_mean', 'elbo_mean', 'nll_mean', 'kld_mean', 'additional_loss_mean', 'mut_info_mean'):
+        close(out[k], ref[k], rtol=1e-5, atol=1e-4)
+    grads = torch.autograd.grad(out['loss_mean'], leaves, allow_unused=True)
+    for i, s in enumerate(g['steps']):
+        for j, k in enumerate(('enc_logits', 'prior_logits', 'xhat_logits', 'recon')):
+            mine, want = grads[4 * i + j], s['grad_' + k]
+            if want is None:
+                assert mine is None or float(mine.abs().max()) == 0.0
+            else:
+                close(mine, want, rtol=1e-4, atol=1e-7)
+    # a second call goes on from where the annealer stands (calls 5..8), as the reference's would
+    model.loss_function([r.detach() for r in recons], xs[0] if additive else xs, params)
+    assert model.kl_annealer.seen[4:] == [0.5 * min(1.0, n / 8.0) for n in range(5, 9)]
+
+
+def test_vrnn_loss_function_own_nll_is_honoured(golden):
+    """abstract_vae.py:344 calls self.nll: a host class that brings its own nll gets the per-step loop with THAT nll
+    (here twice the Bernoulli NLL), not the fused launch's."""
+    g = golden('vrnnloss')['vrnnloss_vrnn']
+    c = dict(g['config'], cuda=True)
+
+    def twice(self, x, recon_x, nll_type):
+        from vae_amd import functional as F_
+        return 2.0 * F_.nll(x, recon_x, nll_type)
+
+    model = _vrnn_host(c, own_nll=twice)
+    assert model._own_nll()
+    recons, xs, params, _ = _golden_vrnn_steps(g, model)
+    out = model.loss_function(recons, xs, params)
+    plain = _vrnn_host(c)
+    assert not plain._own_nll()
+    r2, x2, p2, _ = _golden_vrnn_steps(g, plain)
+    ref = plain.loss_function(r2, x2, p2)
+    close(out['nll_mean'], 2.0 * ref['nll_mean'], rtol=1e-5, atol=1e-5)
+    close(out['mut_info_mean'], ref['mut_info_mean'], rtol=1e-6, atol=1e-6)
+    close(out['loss'] - out['elbo'], ref['loss'] - ref['elbo'], rtol=1e-4, atol=1e-4)   # (beta - 1) kld - mi: nll-free
+    assert out['kl_beta_scalar'] == pytest.approx(ref['kl_beta_scalar'])
+
+
+def test_elbo_mixin_own_nll_is_honoured():
+    """ELBOMixin.loss_function with an overridden nll (K = 1 and K = 3): the override's values reach the loss dict."""
+    from vae_amd.elbo import ELBOMixin
+    from vae_amd.reparameterizers import IsotropicGaussian
+    from vae_amd import functional as F_
+    torch.manual_seed(21)
+    B, L = 40, 8
+    c = cfg(continuous_size=2 * L, kl_beta=0.3)
+    dec = torch.nn.Linear(L, 784).to(DEV)
+
+    class Host(ELBOMixin, torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.config = c
+            self.reparameterizer = IsotropicGaussian(c)
+            self.calls = 0
+
+        def decode(self, z):
+            return dec(z)
+
+        def nll(self, x, recon_x, nll_type):
+            self.calls += 1
+            return 3.0 * F_.nll(x, recon_x, nll_type) + 1.0
+
+    m = Host().train()
+    x = (torch.rand(B, 784, device=DEV) < 0.2).float()
+    logits = torch.randn(B, 2 * L, device=DEV)
+    noise = torch.randn(B, L, device=DEV)
+    z, params = m.reparameterizer(logits, noise=noise)
+    recon = dec(z)
+    out = m.loss_function(recon, x, params)
+    assert m.calls == 1
+    base = F_.nll(x, recon, 'bernoulli')
+    kld = m.kld(params)
+    ref = O.loss_function((3.0 * base + 1.0).cpu(), kld.cpu(), kl_beta=0.3)
+    for k in ('loss', 'elbo', 'loss_mean', 'nll_mean', 'kld_mean'):
+        close(out[k], ref[k], rtol=1e-5, atol=1e-3)
+    m.calls = 0
+    out3 = m.loss_function(recon, x, params, K=3)
+    assert m.calls == 3 and out3['loss'].shape == (B,)
+
+
+def test_vrnn_loss_per_step_beta_T64_vs_per_step_oracle():
+    """T = 64 x B = 256 with a different KL weight at every step, a mutual-information vector and the prior KL:
+    the step-table launch against the per-step oracle loop, forward and gradients (incl. d kld, d mi)."""
+    from vae_amd import functional as F_
+    torch.manual_seed(31)
+    T, B, D = 64, 256, 784
+    betas = [0.01 * (t + 1) for t in range(T)]
+    xs = [(torch.rand(B, D) < 0.2).float() for _ in range(T)]
+    recons = [torch.randn(B, D) for _ in range(T)]
+    kld, mi = torch.rand(T * B) * 20, torch.randn(T * B)
+    r0 = [r.clone().requires_grad_(True) for r in recons]
+    k0, m0 = kld.clone().requires_grad_(True), mi.clone().requires_grad_(True)
+    steps0 = [O.loss_function(O.nll(xs[t], r0[t], 'bernoulli'), k0[t * B:(t + 1) * B], betas[t], mut_info=m0[t * B:(t + 1) * B])
+              for t in range(T)]
+    ref = O.vrnn_loss(steps0)
+    w = torch.randn(B)
+    g0 = torch.autograd.grad(ref['loss_mean'] + (ref['loss'] * w).sum() / B, [r0[5], k0, m0])
+    r1 = [r.to(DEV).requires_grad_(True) for r in recons]
+    k1, m1 = kld.to(DEV).requires_grad_(True), mi.to(DEV).requires_grad_(True)
+    _, _, _, means, la, ea = F_.nll_steps_elbo([x.to(DEV) for x in xs], r1, 'bernoulli', kld=k1, mi=m1, kl_beta=betas)
+    close(la, ref['loss'], rtol=1e-5, atol=1e-3)
+    close(ea, ref['elbo'], rtol=1e-5, atol=1e-3)
+    for i, k in enumerate(('loss_mean', 'elbo_mean', 'nll_mean', 'kld_mean', 'additional_loss_mean', 'mut_info_mean')):
+        close(means[i], ref[k], rtol=1e-5, atol=1e-4)
+    g1 = torch.autograd.grad(means[0] + (la * w.to(DEV)).sum() / B, [r1[5], k1, m1])
+    for a, b in zip(g1, g0):
+        close(a, b, rtol=1e-4, atol=1e-9)
+
+
 def test_vrnn_time_batched_loss_vs_per_step_oracle():
     """T steps scored in one launch over [T*B] rows == the reference's per-step loop + _mean_map."""
     from vae_amd import vrnn as V

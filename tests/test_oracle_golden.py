@@ -196,6 +196,42 @@ def test_vrnn(golden):
             assert agg[k] == pytest.approx(v)
 
 
+@pytest.mark.parametrize('name', ['vrnnloss_vrnn', 'vrnnloss_additive'])
+def test_vrnn_loss_function(golden, name):
+    """VRNN.loss_function itself with use_prior_kl, a clamped mutual-information term and a stateful KL annealer
+    (vrnn.py:751-765,805-829; abstract_vae.py:319-330,360-363): the oracle's per-step loop against the reference's."""
+    g = golden('vrnnloss')[name]
+    c = g['config']
+    leaves, recons, xs, params = [], [], [], []
+    for s in g['steps']:
+        enc, pri, xhat, recon = (s[k].clone().requires_grad_(True) for k in ('enc_logits', 'prior_logits',
+                                                                             'xhat_logits', 'recon'))
+        _, p = O.vrnn_reparameterize(enc, pri, s['noise_post'], s['noise_prior'])
+        _, q = O.gauss_forward(xhat, s['noise_xhat'])
+        p['posterior']['q_z_given_xhat'] = q
+        close(O.vrnn_mut_info(p, c['continuous_mut_info'], c['mut_clamp_strategy'], c['mut_clamp_value']), s['mut_info'])
+        close(O.vrnn_kld(p, c['use_prior_kl']), s['kld'], rtol=1e-6, atol=1e-5)
+        leaves += [enc, pri, xhat, recon]
+        recons.append(recon)
+        xs.append(s['x'])
+        params.append(p)
+    additive = name.endswith('additive')
+    out = O.vrnn_loss_function(recons, xs[0] if additive else xs, params, c['nll_type'], g['kl_betas'],
+                               use_prior_kl=c['use_prior_kl'], mi_scale=c['continuous_mut_info'],
+                               strategy=c['mut_clamp_strategy'], value=c['mut_clamp_value'], additive=additive)
+    ref = g['result']
+    assert out['count'] == ref['count'] and abs(out['kl_beta_scalar'] - ref['kl_beta_scalar']) < 1e-12
+    for k in ('loss', 'elbo', 'loss_mean', 'elbo_mean', 'nll_mean', 'kld_mean', 'additional_loss_mean', 'mut_info_mean'):
+        close(out[k], ref[k], rtol=1e-6, atol=1e-5)
+    grads = torch.autograd.grad(out['loss_mean'], leaves, allow_unused=True)
+    for i, s in enumerate(g['steps']):
+        for j, k in enumerate(('enc_logits', 'prior_logits', 'xhat_logits', 'recon')):
+            if s['grad_' + k] is None:
+                assert grads[4 * i + j] is None or float(grads[4 * i + j].abs().max()) == 0.0
+            else:
+                close(grads[4 * i + j], s['grad_' + k], rtol=1e-5, atol=1e-7)
+
+
 def test_multi_loss_k3(golden):
     """abstract_vae.py:347-354 through the reference (stub model): draw order, K-average, combine."""
     g = golden('multi')['multi_lossK3']

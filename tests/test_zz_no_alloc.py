@@ -33,8 +33,12 @@ def _run(name, x, recon, kld, nll_type, dtype_code, with_ws):
 def test_static_scratch_matches_workspace_entry_point(nll_type, dtype):
     code = {torch.float32: 0, torch.bfloat16: 1}[dtype]
     g = torch.Generator(device=DEV).manual_seed(7 + nll_type)
-    # a big call first, then a smaller one: stale partials / counters of the first must not leak into the second
-    for B, D in ((4099, 784), (37, 784), (1, 16)):
+    # a big call first, then smaller ones: stale partials / counters of the first must not leak into the next.
+    # The first two sizes force the MULTI-BLOCK closing launch (more than 8 * 256 vectors of per-sample values:
+    # B > 8192 in fp32, > 16384 in the 16-bit types), i.e. the path that really uses the __device__ scratch -- the
+    # arrival counter, the block partials, the address from hipGetSymbolAddress; the last two close in one block.
+    big = (70001, 9001) if dtype == torch.float32 else (70001, 17001)
+    for B, D in ((big[0], 784), (big[1], 784), (37, 784), (1, 16)):
         x = torch.rand(B, D, generator=g, device=DEV).to(dtype)
         recon = torch.randn(B, D if nll_type == 0 else 2 * D, generator=g, device=DEV).to(dtype)
         kld = torch.rand(B, generator=g, device=DEV).to(dtype)
@@ -43,6 +47,31 @@ def test_static_scratch_matches_workspace_entry_point(nll_type, dtype):
         for r, o, what in zip(ref, got, ('nll', 'loss', 'elbo', 'means', 'grecon')):
             assert not bool(torch.isnan(o.float()).any()), what
             assert torch.equal(r, o), (what, B, D)
+
+
+def test_static_scratch_nan_word():
+    """A NaN sample in a multi-block call raises the sticky word of the static scratch (read with workspace = NULL),
+    and only there; clearing it works."""
+    from vae_amd import _lib
+    from vae_amd._lib import call
+    g = torch.Generator(device=DEV).manual_seed(3)
+    B, D = 20001, 64
+    x = torch.rand(B, D, generator=g, device=DEV)
+    recon = torch.randn(B, D, generator=g, device=DEV)
+    kld = torch.rand(B, generator=g, device=DEV)
+    st = _lib.stream_ptr(torch.device(DEV))
+    out = ctypes.c_uint32(99)
+    call('vae_nan_flag', None, 1, ctypes.byref(out), st)            # start clean
+    _run('vae_nll_elbo_fused_static', x, recon, kld, 0, 0, False)
+    call('vae_nan_flag', None, 0, ctypes.byref(out), st)
+    assert out.value == 0
+    recon[12345, 7] = float('nan')
+    got = _run('vae_nll_elbo_fused_static', x, recon, kld, 0, 0, False)
+    assert bool(torch.isnan(got[3][0]))                             # loss_mean
+    call('vae_nan_flag', None, 1, ctypes.byref(out), st)
+    assert out.value & 1                                            # VAE_NAN_NLL
+    call('vae_nan_flag', None, 0, ctypes.byref(out), st)
+    assert out.value == 0                                           # cleared by the previous read
 
 
 def test_static_scratch_rejects_oversize():

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be imported before the CDLL below, see module 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VAE_AMD_LIB') or os.path.join(_HERE, 'libvae_amd.so')  # env override: tuning builds only
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 VAE_OK, VAE_ERR_ARG, VAE_ERR_LAUNCH = 0, 1, 2
 VAE_F32, VAE_BF16, VAE_F16 = 0, 1, 2
@@ -22,6 +22,7 @@ NLL_TYPES = {'bernoulli': 0, 'gaussian': 1, 'disc_logistic': 2, 'log_logistic_25
 
 _p, _i64, _u64, _f, _i = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float, ctypes.c_int
 _pp = ctypes.POINTER(ctypes.c_void_p)   # host array of device pointers
+_fp = ctypes.POINTER(ctypes.c_float)    # host array of floats
 
 # name -> argtypes; mirrors include/vae_amd.h one to one (tests/test_abi.py checks the symbols)
 SIGNATURES = {
@@ -68,8 +69,9 @@ SIGNATURES = {
                                     _p],
     'vae_nll_multi_elbo_fwd': [_p, _pp, _i64, _i, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
     'vae_nll_multi_elbo_bwd': [_p, _pp, _pp, _i64, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i64, _i64, _i, _p],
-    'vae_nll_steps_elbo_fwd': [_pp, _pp, _i64, _i, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
-    'vae_nll_steps_elbo_bwd': [_pp, _pp, _pp, _i64, _i, _p, _p, _p, _p, _f, _f, _p, _i64, _i64, _i, _p],
+    'vae_nll_steps_elbo_fwd': [_pp, _pp, _i64, _i, _p, _p, _p, _fp, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64,
+                               _i, _p],
+    'vae_nll_steps_elbo_bwd': [_pp, _pp, _pp, _i64, _i, _p, _p, _p, _p, _fp, _f, _f, _p, _p, _p, _i64, _i64, _i, _p],
     'vae_made_tail_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _i, _p],
     'vae_made_tail_bwd': [_p, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i, _i, _p],
     'vae_coupling_tail_fwd': [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
@@ -136,6 +138,11 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def float_array(values):
+    """Host array of floats (the per-step KL weights of the step-table NLL), or None."""
+    return None if values is None else (ctypes.c_float * len(values))(*[float(v) for v in values])
+
+
 def ptr_array(tensors):
     """Host array of device pointers (the multi-sample NLL takes its S decoder outputs this way)."""
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
@@ -178,7 +185,9 @@ def nan_flags(device=None, clear=True):
     """OR of the sticky saw-a-NaN words (include/vae_amd.h: VAE_NAN_*) of every workspace this process holds on
     `device` (default: the current one).  Synchronises the streams those workspaces belong to: meant for the end of
     an epoch or every N steps -- the kernels raise the bits without any host involvement (the reference's
-    nan_check_and_break, abstract_vae.py:366-369, synchronises on every step instead)."""
+    nan_check_and_break, abstract_vae.py:366-369, synchronises on every step instead).  The word of the library's
+    static scratch (vae_nll_elbo_fused_static: callers of the C ABI only, nothing in this package launches it) is
+    included: vae_nan_flag with workspace = NULL reads that one."""
     index = torch.cuda.current_device() if device is None else torch.device(device).index
     index = torch.cuda.current_device() if index is None else index
     flags = 0
@@ -190,6 +199,8 @@ def nan_flags(device=None, clear=True):
             call('vae_nan_flag', ctypes.c_void_p(ws.data_ptr()), int(bool(clear)), ctypes.byref(out),
                  ctypes.c_void_p(stream))
             flags |= out.value
+        call('vae_nan_flag', None, int(bool(clear)), ctypes.byref(out), stream_ptr(torch.device('cuda', index)))
+        flags |= out.value
     return flags
 
 

@@ -19,7 +19,7 @@ __global__ void rng_reset_kernel() { g_graph_calls = 0ull; }
 }  // namespace
 
 extern "C" {
-int vae_abi_version(void) { return 10; }
+int vae_abi_version(void) { return 11; }
 
 int vae_rng_next(uint64_t* cell, int64_t n, vae_stream_t stream) {
   if (!cell || n < 1) return VAE_ERR_ARG;

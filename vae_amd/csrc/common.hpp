@@ -665,7 +665,8 @@ inline RowGeom row_geom(int64_t rows, int64_t vecs_per_row, int64_t max_grid = k
   RowGeom g;
   int G = 1;
   while (G < 64 && (int64_t)G * 2 < vecs_per_row) G <<= 1;  // >= 2 vectors per lane and tensor in flight
-  if (kn.G >= 1 && kn.G <= 64 && (kn.G & (kn.G - 1)) == 0) G = kn.G;
+  // a tuning knob never widens the group beyond the row: the kernels assume every lane owns at least one vector
+  if (kn.G >= 1 && kn.G <= 64 && (kn.G & (kn.G - 1)) == 0 && kn.G <= vecs_per_row) G = kn.G;
   g.G = G;
   const int64_t iters = (vecs_per_row + G - 1) / G;
   g.U = iters >= 3 ? 4 : (iters == 2 ? 2 : 1);

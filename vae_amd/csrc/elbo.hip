@@ -52,6 +52,7 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_fwd_kernel(
     const T *xr, *rr;
     T* gr_unused;
     const bool live = src.locate(t, rpb, rloc, D, rstride, row, xr, rr, gr_unused);
+    const float kb = src.beta(t, kl_beta);
     float s = 0.f;
     float k = 0.f, ad = 0.f, m = 0.f;   // requested with the row (see nll_elbo_fused_kernel)
     if (live) {
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_fwd_kernel(
       nll_out[row] = from_f32<T>(n);
       if (loss) {
         const float e = to_f32(from_f32<T>(n + k));
-        const float l = to_f32(from_f32<T>((n + ad + kl_beta * k) - m));
+        const float l = to_f32(from_f32<T>((n + ad + kb * k) - m));
         loss[row] = from_f32<T>(l);
         elbo[row] = from_f32<T>(e);
       }
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_bwd_kernel(
     const float ge = (gelbo ? to_f32(gelbo[row]) : 0.f) + gm[1];
     const float c = (gnll ? to_f32(gnll[row]) : 0.f) + gl + ge + gm[2];
     if (sub == 0) {
-      if (gkld) gkld[row] = from_f32<T>(kl_beta * gl + ge + gm[3]);
+      if (gkld) gkld[row] = from_f32<T>(src.beta(t, kl_beta) * gl + ge + gm[3]);
       if (gadd) gadd[row] = from_f32<T>(gl + gm[4]);
       if (gmi) gmi[row] = from_f32<T>(gm[5] - gl);
     }
@@ -437,11 +438,12 @@ static int nll_bwd_dispatch(const void* x, const void* recon, const void* gnll, 
 // ---- the same over T per-step tensors given by pointer (VRNN / AdditiveVRNN loss_function) ---------------------
 template <typename Tab>
 static bool fill_steps(Tab* tab, const void* const* xs, const void* const* recons, void* const* grecons, int64_t steps,
-                       bool* aligned) {
+                       const float* kl_betas, float kl_beta, bool* aligned) {
   for (int64_t i = 0; i < steps; ++i) {
     if (!xs[i] || !recons[i] || (grecons && !grecons[i])) return false;
     tab->x[i] = xs[i];
     tab->recon[i] = recons[i];
+    tab->beta[i] = kl_betas ? kl_betas[i] : kl_beta;
     if (!aligned16(xs[i]) || !aligned16(recons[i]) || (grecons && !aligned16(grecons[i]))) *aligned = false;
     if constexpr (sizeof(Tab) == sizeof(StepTableG)) tab->grecon[i] = grecons[i];
   }
@@ -450,37 +452,38 @@ static bool fill_steps(Tab* tab, const void* const* xs, const void* const* recon
 
 template <typename T, int NLL>
 static int nll_steps_fwd_dispatch(const void* const* xs, const void* const* recons, int64_t steps, const void* kld,
-                                  void* nll, void* loss, void* elbo, void* loss_avg, void* elbo_avg, void* elbo_lse,
-                                  float* means, float* workspace, int64_t B, int64_t D, float kl_beta, float inv_count,
+                                  const void* add, const void* mi, const float* kl_betas, void* nll, void* loss,
+                                  void* elbo, void* loss_avg, void* elbo_avg, void* elbo_lse, float* means,
+                                  float* workspace, int64_t B, int64_t D, float kl_beta, float inv_count,
                                   hipStream_t stream) {
   constexpr int VN = VecOf<T>::n;
   StepRows<T, StepTable> src;
   bool al = true;
-  if (!fill_steps(&src.tab, xs, recons, nullptr, steps, &al)) return VAE_ERR_ARG;
+  if (!fill_steps(&src.tab, xs, recons, nullptr, steps, kl_betas, kl_beta, &al)) return VAE_ERR_ARG;
   const bool vec = (D % VN == 0) && al;
   const RowGeom g = nll_geom(B * steps, vec ? D / VN : D, kGridStream, false, true);   // geometry by the whole launch
   src.B = B;
   src.tps = (B + g.rows_per_block - 1) / g.rows_per_block;                // tiles never straddle steps
-  nll_fwd_launch<T, NLL>(src, vec, g, src.tps * steps, kld, nullptr, nullptr, nll, loss, elbo, D, kl_beta, stream);
-  launch_rows_means<T>(loss, elbo, nll, kld, nullptr, nullptr, workspace, inv_count, means, B * steps, stream, steps,
-                       loss_avg, elbo_avg, elbo_lse);
+  nll_fwd_launch<T, NLL>(src, vec, g, src.tps * steps, kld, add, mi, nll, loss, elbo, D, kl_beta, stream);
+  launch_rows_means<T>(loss, elbo, nll, kld, add, mi, workspace, inv_count, means, B * steps, stream, steps, loss_avg,
+                       elbo_avg, elbo_lse);
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 
 template <typename T, int NLL>
 static int nll_steps_bwd_dispatch(const void* const* xs, const void* const* recons, void* const* grecons, int64_t steps,
                                   const void* gnll, const void* gloss, const void* gelbo, const float* gmeans,
-                                  void* gkld, int64_t B, int64_t D, float kl_beta, float inv_count,
-                                  hipStream_t stream) {
+                                  const float* kl_betas, void* gkld, void* gadd, void* gmi, int64_t B, int64_t D,
+                                  float kl_beta, float inv_count, hipStream_t stream) {
   constexpr int VN = VecOf<T>::n;
   StepRows<T, StepTableG> src;
   bool al = true;
-  if (!fill_steps(&src.tab, xs, recons, grecons, steps, &al)) return VAE_ERR_ARG;
+  if (!fill_steps(&src.tab, xs, recons, grecons, steps, kl_betas, kl_beta, &al)) return VAE_ERR_ARG;
   const bool vec = (D % VN == 0) && al;
   const RowGeom g = nll_geom(B * steps, vec ? D / VN : D, kGridStream, true);
   src.B = B;
   src.tps = (B + g.rows_per_block - 1) / g.rows_per_block;
-  nll_bwd_launch<T, NLL>(src, vec, g, src.tps * steps, B * steps, gnll, gloss, gelbo, gmeans, gkld, nullptr, nullptr, D,
+  nll_bwd_launch<T, NLL>(src, vec, g, src.tps * steps, B * steps, gnll, gloss, gelbo, gmeans, gkld, gadd, gmi, D,
                          kl_beta, inv_count, stream);
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
@@ -596,17 +599,18 @@ int vae_nll_elbo_bwd(const void* x, const void* recon, int nll_type, const void*
 }
 
 int vae_nll_steps_elbo_fwd(const void* const* xs, const void* const* recons, int64_t steps, int nll_type,
-                           const void* kld, float kl_beta, float inv_count, void* nll, void* loss, void* elbo,
-                           void* loss_avg, void* elbo_avg, void* elbo_lse, float* means, float* workspace, int64_t B,
-                           int64_t D, int dtype, vae_stream_t stream) {
+                           const void* kld, const void* add, const void* mi, const float* kl_betas, float kl_beta,
+                           float inv_count, void* nll, void* loss, void* elbo, void* loss_avg, void* elbo_avg,
+                           void* elbo_lse, float* means, float* workspace, int64_t B, int64_t D, int dtype,
+                           vae_stream_t stream) {
   if (B < 0 || D <= 0 || D > VAE_MAX_ROW || steps < 1 || steps > VAE_MAX_STEPS) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
   if (!xs || !recons || !nll || !loss || !elbo || !means || !workspace) return VAE_ERR_ARG;
   if ((loss_avg == nullptr) != (elbo_avg == nullptr)) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
 #define VAE_STEPS_FWD(TT, NN)                                                                                        \
-  return nll_steps_fwd_dispatch<TT, NN>(xs, recons, steps, kld, nll, loss, elbo, loss_avg, elbo_avg, elbo_lse, means, \
-                                        workspace, B, D, kl_beta, inv_count, st)
+  return nll_steps_fwd_dispatch<TT, NN>(xs, recons, steps, kld, add, mi, kl_betas, nll, loss, elbo, loss_avg,        \
+                                        elbo_avg, elbo_lse, means, workspace, B, D, kl_beta, inv_count, st)
 #define VAE_STEPS_FWD_T(TT)                                       \
   switch (nll_type) {                                             \
     case VAE_NLL_BERNOULLI: VAE_STEPS_FWD(TT, VAE_NLL_BERNOULLI); \
@@ -624,15 +628,15 @@ int vae_nll_steps_elbo_fwd(const void* const* xs, const void* const* recons, int
 
 int vae_nll_steps_elbo_bwd(const void* const* xs, const void* const* recons, void* const* grecons, int64_t steps,
                            int nll_type, const void* gnll, const void* gloss, const void* gelbo, const float* gmeans,
-                           float kl_beta, float inv_count, void* gkld, int64_t B, int64_t D, int dtype,
-                           vae_stream_t stream) {
+                           const float* kl_betas, float kl_beta, float inv_count, void* gkld, void* gadd, void* gmi,
+                           int64_t B, int64_t D, int dtype, vae_stream_t stream) {
   if (B < 0 || D <= 0 || D > VAE_MAX_ROW || steps < 1 || steps > VAE_MAX_STEPS) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
   if (!xs || !recons || !grecons) return VAE_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
 #define VAE_STEPS_BWD(TT, NN)                                                                                       \
-  return nll_steps_bwd_dispatch<TT, NN>(xs, recons, grecons, steps, gnll, gloss, gelbo, gmeans, gkld, B, D, kl_beta, \
-                                        inv_count, st)
+  return nll_steps_bwd_dispatch<TT, NN>(xs, recons, grecons, steps, gnll, gloss, gelbo, gmeans, kl_betas, gkld,     \
+                                        gadd, gmi, B, D, kl_beta, inv_count, st)
 #define VAE_STEPS_BWD_T(TT)                                       \
   switch (nll_type) {                                             \
     case VAE_NLL_BERNOULLI: VAE_STEPS_BWD(TT, VAE_NLL_BERNOULLI); \

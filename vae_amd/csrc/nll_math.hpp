@@ -95,15 +95,21 @@ struct FlatRows {
     gr = grecon + row * rstride;
     return true;
   }
+  // the KL weight of the tile's rows: one value for the whole launch
+  __device__ __forceinline__ float beta(int64_t, float kl_beta) const { return kl_beta; }
 };
+// `beta`: the KL weight of each step.  The reference calls compute_kl_beta once per time step
+// (vrnn.py:825-827 -> abstract_vae.py:363), so a stateful annealer hands every step its own value.
 struct StepTable {
   const void* x[VAE_MAX_STEPS];
   const void* recon[VAE_MAX_STEPS];
+  float beta[VAE_MAX_STEPS];
 };
 struct StepTableG {
   const void* x[VAE_MAX_STEPS];
   const void* recon[VAE_MAX_STEPS];
   void* grecon[VAE_MAX_STEPS];
+  float beta[VAE_MAX_STEPS];
 };
 template <typename T, typename Tab>
 struct StepRows {
@@ -122,6 +128,7 @@ struct StepRows {
     else gr = nullptr;
     return true;
   }
+  __device__ __forceinline__ float beta(int64_t tile, float) const { return tab.beta[tile / tps]; }
 };
 
 // Long rows with few samples: give a row to the whole block so the chip stays full.

@@ -69,6 +69,18 @@ def loss_function(recon_x, x, kld, nll_type, kl_beta=1.0, mut_info=None, extra_l
     return _pack(loss, elbo, means, kl_beta, loss.dtype)
 
 
+def clamp_mut_info(config, mut_info):
+    """abstract_vae.py:473-488."""
+    strategy = config['mut_clamp_strategy'].strip().lower()
+    if strategy == 'norm':
+        return mut_info / torch.norm(mut_info, p=2)
+    if strategy == 'clamp':
+        return torch.clamp(mut_info, min=-config['mut_clamp_value'], max=config['mut_clamp_value'])
+    if strategy != 'none':
+        raise KeyError(strategy)
+    return mut_info
+
+
 def vrnn_loss_function(step_losses):
     """vrnn.py:767-829: per-step loss dicts summed, then every entry divided by the step count."""
     agg = None
@@ -100,7 +112,7 @@ class ELBOMixin(object):
         (call model.nan_check(force=True) or vae_amd.nan_flags() at the end of an epoch)."""
         every = int(self.config.get('vae_amd_nan_check', 0) or 0)
         if not force:
-            if every <= 0:
+            if every <= 0 or rng.capturing():   # reading the word synchronises the stream: never inside a graph capture
                 return
             self._nan_check_calls += 1
             if self._nan_check_calls % every:
@@ -141,15 +153,30 @@ class ELBOMixin(object):
         return None  # the reference's zeros[B]; the kernel treats a missing term as 0
 
     def _clamp_mut_info(self, mut_info):
-        strategy = self.config['mut_clamp_strategy'].strip().lower()
-        if strategy == 'norm':
-            return mut_info / torch.norm(mut_info, p=2)
-        if strategy == 'clamp':
-            return torch.clamp(mut_info, min=-self.config['mut_clamp_value'], max=self.config['mut_clamp_value'])
-        return mut_info
+        return clamp_mut_info(self.config, mut_info)
+
+    def _own_nll(self):
+        """True when the host class (or the instance) brings its own `nll`: the reference's loss_function calls
+        self.nll (abstract_vae.py:344, :352), so an override must be honoured, not bypassed by the fused launch."""
+        return getattr(self.nll, '__func__', None) is not ELBOMixin.nll
 
     def loss_function(self, recon_x, x, params, K=1, **extra_loss_terms):
         nll_type = self.config['nll_type']
+        if self._own_nll():
+            # the host's nll, called as the reference calls it (abstract_vae.py:344-354); the combine and the six means
+            # are one launch on its [B] result
+            nll_ = self.nll(x, recon_x, nll_type)
+            if self.training:
+                for _ in range(1, K):
+                    z_k, _ = self.reparameterize(logits=params['logits'], labels=params.get('labels', None))
+                    nll_ = nll_ + self.nll(x, self.decode(z_k), nll_type)
+                nll_ = nll_ / K
+            kl_beta = self.compute_kl_beta([self.config['kl_beta']])[0]
+            out = loss_function(None, x, self.kld(params), nll_type, kl_beta=kl_beta,
+                                mut_info=self.mut_info(params, x.size(0)), extra_loss_terms=extra_loss_terms,
+                                inv_count=self.inv_count, nll_given=nll_)
+            self.nan_check()
+            return out
         if self.training and K > 1:
             # abstract_vae.py:347-354.  The K-1 further draws come from one launch when reparameterize() is
             # the stock one; each draw is still decoded by its own decode() call (batch-norm decoders would

@@ -1028,10 +1028,10 @@ class _NllStepsElbo(torch.autograd.Function):
     """T per-step (target, reconstruction) pairs scored as one [T*B] launch, the tensors read where they are."""
 
     @staticmethod
-    def forward(ctx, kld, nll_code, kl_beta, inv_count, T, with_lse, *tensors):
+    def forward(ctx, kld, add, mi, nll_code, kl_beta, kl_betas, inv_count, T, with_lse, *tensors):
         ctx.set_materialize_grads(False)
         xs, recons = tensors[:T], tensors[T:]
-        dev = check_device(kld, *tensors)
+        dev = check_device(kld, add, mi, *tensors)
         B, D = xs[0].shape
         dt = recons[0].dtype
         new = lambda n: torch.empty((n,), dtype=dt, device=dev)
@@ -1039,11 +1039,12 @@ class _NllStepsElbo(torch.autograd.Function):
         lse = new(B) if with_lse else None
         means = _scalars(6, dev, B)
         with _Guard(dev):
-            call('vae_nll_steps_elbo_fwd', _lib.ptr_array(xs), _lib.ptr_array(recons), T, nll_code, ptr(kld), kl_beta,
-                 inv_count, ptr(nll), ptr(loss), ptr(elbo), ptr(loss_avg), ptr(elbo_avg), ptr(lse), ptr(means),
-                 ptr(workspace(dev)), B, D, dtype_code(recons[0]), stream_ptr(dev))
+            call('vae_nll_steps_elbo_fwd', _lib.ptr_array(xs), _lib.ptr_array(recons), T, nll_code, ptr(kld), ptr(add),
+                 ptr(mi), _lib.float_array(kl_betas), kl_beta, inv_count, ptr(nll), ptr(loss), ptr(elbo), ptr(loss_avg),
+                 ptr(elbo_avg), ptr(lse), ptr(means), ptr(workspace(dev)), B, D, dtype_code(recons[0]),
+                 stream_ptr(dev))
         ctx.save_for_backward(*tensors)
-        ctx.cfg = (nll_code, kl_beta, inv_count, T, kld is not None)
+        ctx.cfg = (nll_code, kl_beta, kl_betas, inv_count, T, kld is not None, add is not None, mi is not None)
         if lse is None:
             lse = new(0)
         ctx.mark_non_differentiable(lse)
@@ -1051,7 +1052,7 @@ class _NllStepsElbo(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gnll, gloss, gelbo, gmeans, gloss_avg, gelbo_avg, glse):
-        nll_code, kl_beta, inv_count, T, has_kld = ctx.cfg
+        nll_code, kl_beta, kl_betas, inv_count, T, has_kld, has_add, has_mi = ctx.cfg
         xs, recons = ctx.saved_tensors[:T], ctx.saved_tensors[T:]
         dev = xs[0].device
         B, D = xs[0].shape
@@ -1065,17 +1066,22 @@ class _NllStepsElbo(torch.autograd.Function):
             gelbo = spread if gelbo is None else gelbo + spread
         gmeans = None if gmeans is None else gmeans.contiguous().float()
         grecons = [torch.empty_like(r) for r in recons]
-        gkld = torch.empty((T * B,), dtype=recons[0].dtype, device=dev) if has_kld and ctx.needs_input_grad[0] else None
+        new = lambda: torch.empty((T * B,), dtype=recons[0].dtype, device=dev)
+        gkld = new() if has_kld and ctx.needs_input_grad[0] else None
+        gadd = new() if has_add and ctx.needs_input_grad[1] else None
+        gmi = new() if has_mi and ctx.needs_input_grad[2] else None
         with _Guard(dev):
             call('vae_nll_steps_elbo_bwd', _lib.ptr_array(xs), _lib.ptr_array(recons), _lib.ptr_array(grecons), T,
-                 nll_code, ptr(gnll), ptr(gloss), ptr(gelbo), ptr(gmeans), kl_beta, inv_count, ptr(gkld), B, D,
-                 dtype_code(recons[0]), stream_ptr(dev))
-        return (gkld, None, None, None, None, None) + (None,) * T + tuple(grecons)
+                 nll_code, ptr(gnll), ptr(gloss), ptr(gelbo), ptr(gmeans), _lib.float_array(kl_betas), kl_beta,
+                 inv_count, ptr(gkld), ptr(gadd), ptr(gmi), B, D, dtype_code(recons[0]), stream_ptr(dev))
+        return (gkld, gadd, gmi, None, None, None, None, None, None) + (None,) * T + tuple(grecons)
 
 
-def nll_steps_elbo(xs, recons, nll_type, kld=None, kl_beta=1.0, inv_count=None, with_lse=False):
+def nll_steps_elbo(xs, recons, nll_type, kld=None, add=None, mi=None, kl_beta=1.0, inv_count=None, with_lse=False):
     """The VRNN loss (vrnn.py:805-829) over T = len(recons) time steps in one launch pair: xs / recons are the per-step
-    targets and decoder outputs (a tensor may repeat), kld the per-step KL vectors concatenated [T*B].
+    targets and decoder outputs (a tensor may repeat); kld / add / mi the per-step KL, additional-loss and
+    mutual-information vectors concatenated [T*B] (abstract_vae.py:356-377 runs once per step); kl_beta one float, or a
+    sequence of T floats when the annealer hands every step its own weight (abstract_vae.py:363 is inside the step loop).
     Returns (nll, loss, elbo [T*B], means float32[6], loss_avg, elbo_avg [B]); the means are over all T*B entries
     (= the mean over steps of the per-step means), the averages are per sample over the steps.
     with_lse=True appends logsumexp over the steps of elbo, [B] (not differentiable): the steps are then draws of one
@@ -1089,9 +1095,19 @@ def nll_steps_elbo(xs, recons, nll_type, kld=None, kl_beta=1.0, inv_count=None, 
     for a, b in zip(xf, rf):
         if a.shape != xf[0].shape or b.shape != rf[0].shape or b.dtype != rf[0].dtype:
             raise ValueError("nll_steps_elbo: every step must have the same shapes and dtype")
+    for name, v in (('kld', kld), ('add', add), ('mi', mi)):
+        if v is not None and v.numel() != T * B:
+            raise ValueError("nll_steps_elbo: %s must hold T*B = %d values, got %d" % (name, T * B, v.numel()))
     if inv_count is None:
         inv_count = 1.0 / max(T * B, 1)
-    out = _NllStepsElbo.apply(_dense(kld), code, float(kl_beta), float(inv_count), T, bool(with_lse), *xf, *rf)
+    kl_betas = None
+    if isinstance(kl_beta, (list, tuple)):
+        if len(kl_beta) != T:
+            raise ValueError("nll_steps_elbo: %d KL weights for %d steps" % (len(kl_beta), T))
+        kl_betas = tuple(float(b) for b in kl_beta)
+        kl_beta = kl_betas[0]
+    out = _NllStepsElbo.apply(_dense(kld), _dense(add), _dense(mi), code, float(kl_beta), kl_betas, float(inv_count), T,
+                              bool(with_lse), *xf, *rf)
     return out if with_lse else out[:6]
 
 
