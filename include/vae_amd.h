@@ -178,6 +178,36 @@ int vae_categorical_kl_fwd(const void* log_q, int64_t stride_q, const void* log_
 int vae_categorical_kl_bwd(const void* log_q, int64_t stride_q, const void* log_p, int64_t stride_p, const void* gkl,
                            void* g_log_q, void* g_log_p, int64_t B, int64_t K, int dtype, vae_stream_t stream);
 
+/* ---- ConcatReparameterizer(['isotropic_gaussian', 'discrete']) as one row kernel ------------------------
+ * reparameterizers/concat_reparameterizer.py:110-118 (per child: narrow -> forward -> clone, then torch.cat) with
+ * the two children of BASELINE config 3, isotropic_gaussian.py:77-131,158-170,204-215 and gumbel.py:110-124,257-304;
+ * KL of the pair = the Gaussian child's (the Gumbel child's is identically 0 without a prior, gumbel.py:239-254).
+ * A lane group owns the whole contiguous logits row [mu(L) | s(L) | categorical logits(K)] and writes the whole
+ * sample row: one launch per direction instead of one per child over strided half rows.
+ *   logits [B, 2L+K] rows `row_stride` apart; noise [B, L] / unif [B, K] or NULL (Philox, one (seed, offset) per
+ *   child as the per-child entry points take them);
+ *   training != 0: z_out [B, L+K] = [z | y]; y, log_q_z may be NULL;
+ *   training == 0: z_out = [mu | z_hard]; y [B, K] and log_q_z [B, K] each written when non-NULL;
+ *   kl [B].  noise and unif are given together or not at all.  The Gaussian child's two mean diagnostics
+ *   (isotropic_gaussian.py:213-214) are not produced here (a grid-wide sum costs this launch 8-12 us): the module
+ *   class forms them on first read with torch.mean, as the reference does.
+ * Needs L and K multiples of 4 (8 for the 16-bit types), 16-byte aligned bases and strides, and rows that stay
+ * register-resident (L/4, K/4 <= 256 vectors): vae_concat_gauss_gumbel_supported tells; VAE_ERR_ARG otherwise
+ * (run the children one by one through vae_gauss_reparam_kl_* / vae_gumbel_*, which take the same slices).   */
+int vae_concat_gauss_gumbel_supported(int64_t L, int64_t K, int dtype);
+int vae_concat_gauss_gumbel_fwd(const void* logits, int64_t row_stride, const void* noise, const void* unif, void* z_out,
+                                int64_t z_stride, void* y, void* log_q_z, void* kl, int64_t B, int64_t L, int64_t K,
+                                float eps_tol, float tau, int training, uint64_t seed_gauss, uint64_t offset_gauss,
+                                uint64_t seed_gumbel, uint64_t offset_gumbel, int64_t row0, int dtype,
+                                vae_stream_t stream);
+/* Backward of the training-mode forward: glogits [B, 2L+K] from gz [B, L+K] (gradient of the sample row; NULL = none)
+ * and gkl [B] (may be NULL); z_out is the forward's sample row (its second part is y).                        */
+int vae_concat_gauss_gumbel_bwd(const void* logits, int64_t row_stride, const void* noise, const void* z_out,
+                                int64_t z_stride, const void* gz, int64_t gz_stride, const void* gkl, void* glogits,
+                                int64_t glogits_stride, int64_t B, int64_t L, int64_t K, float eps_tol, float tau,
+                                uint64_t seed_gauss, uint64_t offset_gauss, int64_t row0, int dtype,
+                                vae_stream_t stream);
+
 /* ---- Bernoulli (relaxed) ----------------------------------------------------
  * reparameterizers/bernoulli.py:126-136 via torch/distributions/relaxed_bernoulli.py:104-112
  * (p = clamp(sigmoid(l)), u = clamp(U), y = sigmoid((log u - log1p(-u) + log p - log1p(-p))/tau)),

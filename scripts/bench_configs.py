@@ -126,16 +126,40 @@ def gumbel(B, K, philox=False):
 
 
 def concat(B, L, K):
+    """Concat(Gaussian L, Gumbel K) on one [B, 2L+K] logits buffer: the per-child launches over strided slices (r02)
+    and the one-launch row kernel (csrc/concat.hip), eval (all outputs) and training (sample row only)."""
     W = 2 * L + K
     logits, noise, U = T(B, W), T(B, L), T(B, K, kind='rand')
     z, lv, kl, means = T(B, L, kind='e'), T(B, L, kind='e'), T(B, kind='e'), torch.zeros(2, device=dev)
     y, zh, lq = [T(B, K, kind='e') for _ in range(3)]
+    zcat, gz, gkl, gl = T(B, L + K, kind='e'), T(B, L + K), T(B), T(B, W, kind='e')
     disc = ctypes.c_void_p(logits.data_ptr() + 2 * L * 4)
+    shape = 'B=%d L=%d K=%d f32' % (B, L, K)
+    ms = 1.0 / (B * L)
 
     def fn():
-        call('vae_gauss_reparam_kl_fwd', ptr(logits), W, ptr(noise), ptr(z), 0, ptr(lv), ptr(kl), ptr(means), ptr(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, 0, st)
+        call('vae_gauss_reparam_kl_fwd', ptr(logits), W, ptr(noise), ptr(z), 0, ptr(lv), ptr(kl), ptr(means), ptr(ws), B, L, 1e-6, ms, 1, 0, 0, 0, 0, st)
         call('vae_gumbel_fwd', disc, W, ptr(U), ptr(y), 0, ptr(zh), 0, ptr(lq), B, K, 1.0, 0, 0, 0, 0, st)
-    timeit('concat fwd (gauss+gumbel)', 'B=%d L=%d K=%d f32, strided views of one logits buffer' % (B, L, K), fn, B * (16 * L + 4 + 20 * K))
+    timeit('concat fwd (gauss+gumbel)', shape + ', per-child launches on strided views, all outputs', fn, B * (16 * L + 4 + 20 * K))
+
+    def row(training, inj):
+        return lambda: call('vae_concat_gauss_gumbel_fwd', ptr(logits), W, ptr(noise) if inj and training else None, ptr(U) if inj else None,
+                            ptr(zcat), 0, None if training else ptr(y), None if training else ptr(lq), ptr(kl),
+                            B, L, K, 1e-6, 1.0, int(training), 1, 1, 1, 2, 0, 0, st)
+    # eval, all outputs: logits 4W + noise-free Gaussian (z = mu) + U 4K in; [mu | z_hard] 4(L+K) + y 4K + log_q_z 4K + kl out
+    timeit('concat fwd row kernel', shape + ' eval: [mu|z_hard] + y + log_q_z, injected U', row(False, True),
+           B * (4 * W + 4 * K + 4 * (L + K) + 8 * K + 4))
+    timeit('concat fwd row kernel', shape + ' training: [z|y], injected noise', row(True, True),
+           B * (4 * W + 4 * (L + K) + 4 * (L + K) + 4))
+    timeit('concat fwd row kernel', shape + ' training: [z|y], in-kernel Philox', row(True, False),
+           B * (4 * W + 4 * (L + K) + 4))
+
+    def bwd(inj):
+        return lambda: call('vae_concat_gauss_gumbel_bwd', ptr(logits), W, ptr(noise) if inj else None, ptr(zcat), 0, ptr(gz), 0,
+                            ptr(gkl), ptr(gl), 0, B, L, K, 1e-6, 1.0, 1, 1, 0, 0, st)
+    # logits' Gaussian part 8L + noise 4L + gz 4(L+K) + y 4K + gkl in; d(logits) 4W out
+    timeit('concat bwd row kernel', shape + ' training, injected noise', bwd(True), B * (8 * L + 4 * L + 4 * (L + K) + 4 * K + 4 + 4 * W))
+    timeit('concat bwd row kernel', shape + ' training, in-kernel Philox', bwd(False), B * (8 * L + 4 * (L + K) + 4 * K + 4 + 4 * W))
 
 
 def concat_module(B, L, K):
@@ -170,15 +194,24 @@ def concat_module(B, L, K):
     nb2 = nbytes - B * 4 * (L + K + L)       # no noise tensors read
     cfg2 = 'B=%d L=%d K=%d f32 module fwd+kl+bwd, in-kernel noise' % (B, L, K)
     timeit('concat step (eager)', cfg2, fn2, nb2)
+    # a fresh leaf for the captured step: autograd ties a leaf's AccumulateGrad node to the stream of its first
+    # backward; one created on the default stream drags that stream into the capture (torch warns, HIP then
+    # crashes in hipStreamEndCapture)
+    lg = logits.detach().clone().requires_grad_(True)
+
+    def fn3():
+        z, params = m(lg)
+        ((z * w).sum() + m.kl(params).sum()).backward()
+        lg.grad = None
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
         for _ in range(3):
-            fn2()
+            fn3()
     torch.cuda.current_stream().wait_stream(s)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
-        fn2()
+        fn3()
     timeit('concat step (HIP graph)', cfg2, graph.replay, nb2)
 
 
@@ -425,49 +458,59 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--json', default=None)
     ap.add_argument('--loop', action='store_true', help='time every launch as a back-to-back loop (warm caches)')
+    ap.add_argument('--sections', default='', help='comma list of: c2 c1 c3 c4 tails c5 multi bernbeta (default: all)')
     args = ap.parse_args()
-    print('== C2 family: IsotropicGaussian + Bernoulli NLL sweeps')
-    for B, L in [(4096, 32), (16384, 128), (65536, 512), (65536, 1024)]:
-        gauss(B, L)
-    gauss(65536, 512, philox=True)
-    gauss(65536, 512, dtype=torch.bfloat16)
-    for B in (4096, 16384, 65536):
-        nll(B, 784, 0, 'bernoulli')
-    nll(65536, 784, 0, 'bernoulli', dtype=torch.bfloat16)
-    nll_fused(65536, 784, 0, 'bernoulli')
-    print('== C1-sized steps: eager launches vs one HIP graph')
-    graph_step(4096, 32)
-    graph_step(16384, 128)
-    graph_step(65536, 512)
-    print('== C3: Gumbel-softmax / Concat')
-    for K in (32, 256, 1024):
-        gumbel(65536, K)
-    gumbel(65536, 256, philox=True)
-    concat(65536, 128, 256)
-    concat_module(65536, 128, 256)
-    print('== C4: Gaussian->Flow, 3x64x64 discretized logistic')
-    nll(8192, 12288, 2, 'disc_logistic')
-    nll(8192, 12288, 1, 'gaussian')
-    flow(65536, 512)
-    nll_fused(8192, 12288, 2, 'disc_logistic')
-    nll_fused(8192, 12288, 1, 'gaussian')
-    print('== flow-layer tails (one MAF / RealNVP block)')
-    flowtail(65536, 512)
-    flowtail(65536, 64)
-    print('== C5: VRNN per-step pair (B per step) and the time-batched loss (T*B rows)')
-    gauss(16384, 128)
-    gauss_pair(16384, 128)
-    pair_fused(16384, 128)
-    pair_fused(4096, 32)
-    nll(64 * 1024, 784, 0, 'bernoulli T=64 x B=1024')
-    nll_steps(64, 1024, 784)
-    vrnn_sequence(64, 1024, 128)
-    print('== multi-sample forms (loss_function K > 1, MSGVAE, likelihood)')
-    multi(65536, 512, 784, 4)
-    multi(16384, 128, 784, 8)
-    likelihood(64, 1024)
-    print('== Bernoulli / Beta reparameterizers')
-    bernoulli(65536, 1024)
-    beta(65536, 512)
+    want = [k for k in args.sections.split(',') if k]
+    if not want or 'c2' in want:
+        print('== C2 family: IsotropicGaussian + Bernoulli NLL sweeps')
+        for B, L in [(4096, 32), (16384, 128), (65536, 512), (65536, 1024)]:
+            gauss(B, L)
+        gauss(65536, 512, philox=True)
+        gauss(65536, 512, dtype=torch.bfloat16)
+        for B in (4096, 16384, 65536):
+            nll(B, 784, 0, 'bernoulli')
+        nll(65536, 784, 0, 'bernoulli', dtype=torch.bfloat16)
+        nll_fused(65536, 784, 0, 'bernoulli')
+    if not want or 'c1' in want:
+        print('== C1-sized steps: eager launches vs one HIP graph')
+        graph_step(4096, 32)
+        graph_step(16384, 128)
+        graph_step(65536, 512)
+    if not want or 'c3' in want:
+        print('== C3: Gumbel-softmax / Concat')
+        for K in (32, 256, 1024):
+            gumbel(65536, K)
+        gumbel(65536, 256, philox=True)
+        concat(65536, 128, 256)
+        concat_module(65536, 128, 256)
+    if not want or 'c4' in want:
+        print('== C4: Gaussian->Flow, 3x64x64 discretized logistic')
+        nll(8192, 12288, 2, 'disc_logistic')
+        nll(8192, 12288, 1, 'gaussian')
+        flow(65536, 512)
+        nll_fused(8192, 12288, 2, 'disc_logistic')
+        nll_fused(8192, 12288, 1, 'gaussian')
+    if not want or 'tails' in want:
+        print('== flow-layer tails (one MAF / RealNVP block)')
+        flowtail(65536, 512)
+        flowtail(65536, 64)
+    if not want or 'c5' in want:
+        print('== C5: VRNN per-step pair (B per step) and the time-batched loss (T*B rows)')
+        gauss(16384, 128)
+        gauss_pair(16384, 128)
+        pair_fused(16384, 128)
+        pair_fused(4096, 32)
+        nll(64 * 1024, 784, 0, 'bernoulli T=64 x B=1024')
+        nll_steps(64, 1024, 784)
+        vrnn_sequence(64, 1024, 128)
+    if not want or 'multi' in want:
+        print('== multi-sample forms (loss_function K > 1, MSGVAE, likelihood)')
+        multi(65536, 512, 784, 4)
+        multi(16384, 128, 784, 8)
+        likelihood(64, 1024)
+    if not want or 'bernbeta' in want:
+        print('== Bernoulli / Beta reparameterizers')
+        bernoulli(65536, 1024)
+        beta(65536, 512)
     if args.json:
         json.dump(rows, open(args.json, 'w'), indent=1)

@@ -124,6 +124,80 @@ def test_concat_fused_matches_per_child_path(B, L, K, Kb, train, dtype, monkeypa
         close(g1, g0, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize('B,L,K', [(300, 64, 128), (1025, 36, 12), (64, 512, 1024), (77, 8, 256), (5000, 128, 256),
+                                   (33, 1024, 32)])
+@pytest.mark.parametrize('train', [True, False])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('inject', [True, False])
+def test_concat_row_kernel_matches_per_child_launches(B, L, K, train, dtype, inject, monkeypatch):
+    """Concat(Gaussian, Gumbel) through the one-launch row kernel (csrc/concat.hip: a lane group owns the whole
+    [2L+K] row) against the per-child launches over strided slices, same noise (injected, or the same Philox
+    streams): the Gaussian part and the KL's inputs bit for bit (same roundings), the softmax part to the summation
+    order of the row (another lane-group width), the hard sample's hot positions identical, d(logits) likewise."""
+    from vae_amd import functional as F_
+    from vae_amd import rng
+    from vae_amd.reparameterizers import ConcatReparameterizer
+    if dtype != torch.float32 and (L % 8 or K % 8):
+        pytest.skip('16-bit rows need multiples of 8 for the row kernel')
+    torch.manual_seed(B + L + K)
+    c = cfg(continuous_size=2 * L, discrete_size=K)
+    logits = torch.randn(B, 2 * L + K, device=DEV).to(dtype)
+    noise = [torch.randn(B, L, device=DEV).to(dtype) if train else None,
+             torch.rand(B, K, device=DEV).clamp_(1e-3, 1 - 1e-3).to(dtype)] if inject else None
+    w = torch.randn(B, L + K, device=DEV).to(dtype)
+    assert F_._row_kernel_ok(logits, (('gauss', L, 1e-6, None), ('gumbel', K, 1.0)))
+
+    def run(row_kernel):
+        monkeypatch.setattr(F_, 'ROW_KERNEL', row_kernel)
+        m = ConcatReparameterizer(['isotropic_gaussian', 'discrete'], dict(c))
+        m.train(train)
+        rng.manual_seed(11)
+        x = logits.clone().requires_grad_(True)
+        z, params = m(x, noise=noise)
+        kl = m.kl(params)
+        g0 = params['concat'][0]['gaussian']
+        obj = (z.float() * w.float()).sum() + (kl.float() * 0.5).sum() + g0['mu_mean'].float() + 2 * g0['logvar_mean'].float()
+        (g,) = torch.autograd.grad(obj, x)
+        return z, params, kl, g
+
+    z1, p1, kl1, g1 = run(True)
+    z0, p0, kl0, g0 = run(False)
+    tol = dict(rtol=2e-6, atol=1e-7) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-3)
+    assert z1.shape == (B, L + K) and z1.is_contiguous()
+    assert torch.equal(z1[:, :L], z0[:, :L])                                     # Gaussian sample: bit for bit
+    if train:
+        close(z1[:, L:], z0[:, L:], **tol)
+    else:
+        assert torch.equal(z1[:, L:] == 1, z0[:, L:] == 1)                       # every hot position
+        close(p1['concat'][1]['z'], p0['concat'][1]['z'], **tol)
+    close(kl1, kl0, rtol=1e-5 if dtype == torch.float32 else 1e-2, atol=1e-4 if dtype == torch.float32 else 0.3)
+    d1, d0 = p1['concat'][1]['discrete'], p0['concat'][1]['discrete']
+    assert set(d1) == set(d0)
+    assert torch.equal(d1['z_hard'] == 1, d0['z_hard'] == 1)
+    close(d1['log_q_z'], d0['log_q_z'], rtol=1e-5 if dtype == torch.float32 else 1e-2, atol=1e-5 if dtype == torch.float32 else 5e-2)
+    a1, a0 = p1['concat'][0]['gaussian'], p0['concat'][0]['gaussian']
+    assert torch.equal(a1['logvar'], a0['logvar'])
+    close(a1['mu_mean'], a0['mu_mean'], rtol=1e-5, atol=1e-6 if dtype == torch.float32 else 1e-3)
+    if dtype == torch.float32:
+        close(g1, g0, rtol=1e-5, atol=2e-6)
+    else:
+        close(g1, g0, rtol=2e-2, atol=2e-2)
+
+
+def test_concat_row_kernel_shard_invariant_philox():
+    """In-kernel draws of the row kernel are keyed by the global row: a shard run with its row offset draws what the
+    whole batch drew for those rows, both children."""
+    from vae_amd import functional as F_
+    B, L, K = 1000, 32, 64
+    torch.manual_seed(2)
+    logits = torch.randn(B, 2 * L + K, device=DEV)
+    specs = (('gauss', L, 1e-6, None), ('gumbel', K, 0.8))
+    seeds = ((5, 1), (5, 2))
+    full = F_.concat_leaves(logits, specs, True, (None, None), seeds, row0=0)
+    half = F_.concat_leaves(logits[B // 2:], specs, True, (None, None), seeds, row0=B // 2)
+    assert torch.equal(half[0], full[0][B // 2:]) and torch.equal(half[2], full[2][B // 2:])
+
+
 def test_concat_fused_philox_matches_unfused_streams():
     """Without injected noise both paths draw one (seed, offset) per stochastic child in order, so a
     re-seeded run of either gives the same sample."""

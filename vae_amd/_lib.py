@@ -44,6 +44,11 @@ SIGNATURES = {
                            _i, _u64, _u64, _i64, _i, _p],
     'vae_gumbel_fwd': [_p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _i64, _f, _u64, _u64, _i64, _i, _p],
     'vae_gumbel_bwd': [_p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _f, _i, _p],
+    'vae_concat_gauss_gumbel_supported': [_i64, _i64, _i],
+    'vae_concat_gauss_gumbel_fwd': [_p, _i64, _p, _p, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _f, _f, _i, _u64, _u64,
+                                    _u64, _u64, _i64, _i, _p],
+    'vae_concat_gauss_gumbel_bwd': [_p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _f, _f, _u64,
+                                    _u64, _i64, _i, _p],
     'vae_categorical_kl_fwd': [_p, _i64, _p, _i64, _p, _i64, _i64, _i, _p],
     'vae_categorical_kl_bwd': [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _p],
     'vae_bernoulli_fwd': [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _f, _u64, _u64, _i64, _i, _p],

@@ -541,8 +541,11 @@ struct Philox {
     uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32);
     uint32_t c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#ifndef VAE_PHILOX_ROUNDS
+#define VAE_PHILOX_ROUNDS 10
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < VAE_PHILOX_ROUNDS; ++r) {
       // one 32x32->64 product each (v_mad_u64_u32) instead of a mul_hi + mul_lo pair
       const uint64_t p0 = (uint64_t)kM0 * (uint64_t)c0, p1 = (uint64_t)kM1 * (uint64_t)c2;
       const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
@@ -703,6 +706,9 @@ inline bool row_geom_resident(int64_t rows, int64_t vecs_per_row, int64_t max_gr
   int G = 1;
   while (G < 64 && (int64_t)G * 4 < vecs_per_row) G <<= 1;
   if ((int64_t)G * 4 < vecs_per_row) G = kBlock;
+  // tuning knob: a wider group (fewer chunks per lane, fewer registers), never one that no longer holds the row
+  const Knobs& kn = knobs();
+  if (kn.G > G && kn.G <= 64 && (kn.G & (kn.G - 1)) == 0 && kn.G <= vecs_per_row) G = kn.G;
   g.G = G;
   const int64_t iters = (vecs_per_row + G - 1) / G;
   g.U = iters >= 3 ? 4 : (iters == 2 ? 2 : 1);

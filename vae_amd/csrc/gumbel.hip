@@ -13,17 +13,15 @@
 // The hard mask is computed from y exactly as the reference does (same op order: x - max, exp,
 // times 1/sum as ATen's CPU softmax, == rowmax), so ties give the same multi-hot rows.
 #include "common.hpp"
+#include "gumbel_row.hpp"
 #include "../../include/vae_amd.h"
 
 namespace vae {
 
-constexpr float kGumbelEps = 1e-9f;
-constexpr float kNegInf = -3.402823466e+38f;
-
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
-template <typename T, int V, int U>
+template <typename T, int V, int U, bool INJ>
 __global__ __launch_bounds__(kBlock) void gumbel_fwd_kernel(
     const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ unif, T* __restrict__ y_out,
     int64_t y_stride, T* __restrict__ zh_out, int64_t zh_stride, T* __restrict__ lq_out, int64_t B, int K, float tau, uint64_t seed, uint64_t offset,
@@ -41,116 +39,12 @@ __global__ __launch_bounds__(kBlock) void gumbel_fwd_kernel(
     const int64_t r = live ? row : B - 1;  // dead lane groups shadow the last row (no stores)
     float l[U][V], u[U][V];
     load_chunk<T, V, U>(logits + r * row_stride, sub, G, nvec, l);
-    if (unif && (y_out || zh_out)) load_chunk<T, V, U>(unif + r * K, sub, G, nvec, u);
-
-    // Each output may be absent (kernel-uniform): the module classes write only what the step reads -- y in
-    // training -- and produce z_hard / log_q_z on first read (vae_amd/lazy.py).
-    const bool want_lq = lq_out != nullptr;
-    const bool want_soft = y_out != nullptr || zh_out != nullptr;
-
-    // ---- log_q_z = (l - max) - log(sum exp(l - max))
-    float m1 = kNegInf, lse = 0.f;
-    if (want_lq) {
-#pragma unroll
-      for (int k = 0; k < U; ++k)
-        if (sub + k * G < nvec)
-#pragma unroll
-          for (int i = 0; i < V; ++i) m1 = fmaxf(m1, l[k][i]);
-      m1 = row_max(m1, G);
-      float s1 = 0.f;
-#pragma unroll
-      for (int k = 0; k < U; ++k)
-        if (sub + k * G < nvec)
-#pragma unroll
-          for (int i = 0; i < V; ++i) s1 += exp_acc(sub_rn(l[k][i], m1));
-      s1 = row_sum(s1, G);
-      lse = logf(s1);
+    if constexpr (INJ) {
+      if (y_out || zh_out) load_chunk<T, V, U>(unif + r * K, sub, G, nvec, u);
     }
-    if (!want_soft) {
-      if (live) {
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-          const int j = sub + k * G;
-          if (j < nvec) {
-            float lq[V];
-#pragma unroll
-            for (int i = 0; i < V; ++i) lq[i] = sub_rn(sub_rn(l[k][i], m1), lse);
-            store_vec<T, V>(nts, lq_out + row * K + (int64_t)j * V, lq);
-          }
-        }
-      }
-      continue;
-    }
-
-    // ---- x = (l + g)/tau + eps, g = -log(-log(U + eps) + eps): every op rounds on its own
-    float x[U][V];
-    float m2 = kNegInf;
-#pragma unroll
-    for (int k = 0; k < U; ++k) {
-      const int j = sub + k * G;
-      if (j < nvec) {
-        if (!unif) philox_uniform<V>(seed, offset, (uint64_t)(row0 + r) * (uint64_t)K + (uint64_t)j * V, u[k]);
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-          // injected U: the reference's own roundings (accurate logs).  In-kernel draws have nothing to be
-          // bit-compared with and this path is ALU-bound (Philox + two logs per element): bare v_log_f32, whose
-          // arguments (>= 1e-9) are in the normal range.
-          float g;
-          if (unif) {
-            g = -logf(add_rn(u[k][i], kGumbelEps));
-            g = -logf(add_rn(g, kGumbelEps));
-          } else {
-            g = -fast_log(u[k][i] + kGumbelEps);
-            g = -fast_log(g + kGumbelEps);
-          }
-          g = to_f32(from_f32<T>(g));
-          const float xi = to_f32(from_f32<T>(div_rn(to_f32(from_f32<T>(add_rn(l[k][i], g))), tau)));
-          x[k][i] = to_f32(from_f32<T>(add_rn(xi, kGumbelEps)));
-          m2 = fmaxf(m2, x[k][i]);
-        }
-      }
-    }
-    m2 = row_max(m2, G);
-    float s2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < U; ++k)
-      if (sub + k * G < nvec)
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-          x[k][i] = expf(sub_rn(x[k][i], m2));
-          s2 += x[k][i];
-        }
-    s2 = row_sum(s2, G);
-    const float rinv = div_rn(1.0f, s2);  // ATen's CPU softmax multiplies by the reciprocal
-    float ymax = 0.f;
-#pragma unroll
-    for (int k = 0; k < U; ++k)
-      if (sub + k * G < nvec)
-#pragma unroll
-        for (int i = 0; i < V; ++i) {
-          x[k][i] = to_f32(from_f32<T>(mul_rn(x[k][i], rinv)));
-          ymax = fmaxf(ymax, x[k][i]);
-        }
-    ymax = row_max(ymax, G);
-
-    if (live) {
-#pragma unroll
-      for (int k = 0; k < U; ++k) {
-        const int j = sub + k * G;
-        if (j < nvec) {
-          float zh[V], lq[V];
-#pragma unroll
-          for (int i = 0; i < V; ++i) {
-            const float h = (x[k][i] == ymax) ? 1.0f : 0.0f;
-            zh[i] = add_rn(to_f32(from_f32<T>(sub_rn(h, x[k][i]))), x[k][i]);  // (h - y).detach() + y
-            lq[i] = sub_rn(sub_rn(l[k][i], m1), lse);
-          }
-          if (y_out) store_vec<T, V>(nts, y_out + row * y_stride + (int64_t)j * V, x[k]);
-          if (zh_out) store_vec<T, V>(nts, zh_out + row * zh_stride + (int64_t)j * V, zh);
-          if (want_lq) store_vec<T, V>(nts, lq_out + row * K + (int64_t)j * V, lq);
-        }
-      }
-    }
+    gumbel_row_fwd<T, V, U, INJ>(l, u, y_out ? y_out + r * y_stride : nullptr,
+                                 zh_out ? zh_out + r * zh_stride : nullptr, lq_out ? lq_out + r * K : nullptr, live,
+                                 nts, sub, G, nvec, tau, seed, offset, (uint64_t)(row0 + r) * (uint64_t)K);
   }
 }
 
@@ -550,15 +444,16 @@ static int gumbel_fwd_dispatch(const void* logits, int64_t row_stride, const voi
                          row_stride, (const T*)unif, (T*)y, ys, (T*)zh, zs, (T*)lq, B, (int)K, tau, seed, offset, row0);
     return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
   }
+#define VAE_GUMBEL_FWD(VV, INJ_)                                                                                   \
+  VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gumbel_fwd_kernel<T, VV, U, INJ_>), dim3(g.grid), dim3(kBlock), 0, stream,     \
+                                       (const T*)logits, row_stride, (const T*)unif, (T*)y, ys, (T*)zh, zs, (T*)lq, B, \
+                                       (int)K, tau, seed, offset, row0, g.G, g.tiles))
   if (vec) {
-    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gumbel_fwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                         (const T*)logits, row_stride, (const T*)unif, (T*)y, ys, (T*)zh, zs, (T*)lq, B,
-                                         (int)K, tau, seed, offset, row0, g.G, g.tiles));
+    if (unif) { VAE_GUMBEL_FWD(VN, true); } else { VAE_GUMBEL_FWD(VN, false); }
   } else {
-    VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gumbel_fwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, stream,
-                                         (const T*)logits, row_stride, (const T*)unif, (T*)y, ys, (T*)zh, zs, (T*)lq, B,
-                                         (int)K, tau, seed, offset, row0, g.G, g.tiles));
+    if (unif) { VAE_GUMBEL_FWD(1, true); } else { VAE_GUMBEL_FWD(1, false); }
   }
+#undef VAE_GUMBEL_FWD
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 

@@ -759,9 +759,25 @@ def gauss_pair(enc_logits, prior_logits, noise_post=None, noise_prior=None, eps_
 # logits buffer, write their samples straight into the concatenated output and their gradients
 # straight into ONE d(logits) buffer -- no torch.cat, no narrow-backward zero-fills and adds.
 # --------------------------------------------------------------------------------------
+ROW_KERNEL = True   # tests flip it to compare the one-launch row kernel with the per-child launches
+
+
 def _poff(t, elems):
     import ctypes
     return ctypes.c_void_p(t.data_ptr() + elems * t.element_size())
+
+
+def _row_kernel_ok(logits, specs, noises=(None, None), training=True):
+    """Concat(Gaussian, Gumbel) whose whole row fits the one-launch row kernel (csrc/concat.hip); the two children's
+    noise must come from one source (both injected or both drawn in the kernel)."""
+    if len(specs) != 2 or specs[0][0] != 'gauss' or specs[1][0] != 'gumbel':
+        return False
+    if (noises[1] is None) != (noises[0] is None) and not (noises[0] is None and not training):
+        return False
+    vn = 16 // logits.element_size()
+    if logits.data_ptr() % 16 or logits.stride(0) % vn:
+        return False
+    return bool(_lib.load().vae_concat_gauss_gumbel_supported(specs[0][1], specs[1][1], dtype_code(logits)))
 
 
 class _ConcatLeaves(torch.autograd.Function):
@@ -778,6 +794,24 @@ class _ConcatLeaves(torch.autograd.Function):
         dt = dtype_code(logits)
         new = lambda *s: torch.empty(s, dtype=logits.dtype, device=dev)
         zcat = new(B, W_out)
+        ctx.row_kernel = ROW_KERNEL and B > 0 and _row_kernel_ok(logits, specs, noises, training)
+        if ctx.row_kernel:
+            # the pair of BASELINE config 3: the whole [2L + K] row in ONE launch
+            (_, L, eps_tol, mean_scale), (_, K, tau) = specs
+            empty = logits.new_empty((0,))
+            kl = new(B)
+            means = torch.empty((0,), dtype=torch.float32, device=dev)   # produced on first read by the module class
+            other, lq = (empty, empty) if training else (new(B, K), new(B, K))
+            with _Guard(dev):
+                call('vae_concat_gauss_gumbel_fwd', ptr(logits), rs, ptr(noises[0]), ptr(noises[1]), ptr(zcat), W_out,
+                     None if training else ptr(other), None if training else ptr(lq), ptr(kl), B, L, K, eps_tol, tau,
+                     int(training), seeds[0][0] & _MASK64, seeds[0][1] & _MASK64, seeds[1][0] & _MASK64,
+                     seeds[1][1] & _MASK64, row0, dt, stream_ptr(dev))
+            outs = [zcat, empty, kl, means, other, lq]
+            ctx.specs, ctx.training, ctx.seeds, ctx.row0 = specs, training, seeds, row0
+            ctx.n_noise = len(noises)
+            ctx.save_for_backward(logits, *noises, *outs)
+            return tuple(outs)
         outs, saved = [zcat], []
         i_off = o_off = 0
         st = stream_ptr(dev)
@@ -829,6 +863,14 @@ class _ConcatLeaves(torch.autograd.Function):
         dt = dtype_code(logits)
         gzcat = _dense(gzcat)
         glogits = torch.empty((B, W_in), dtype=logits.dtype, device=dev)
+        if ctx.row_kernel and training and all(g is None for g in (gex[0], gex[2], gex[3], gex[4])):
+            (_, L, eps_tol, _), (_, K, tau) = specs
+            gkl = _dense(gex[1])
+            with _Guard(dev):
+                call('vae_concat_gauss_gumbel_bwd', ptr(logits), rs, ptr(noises[0]), ptr(zcat), W_out, ptr(gzcat),
+                     W_out, ptr(gkl), ptr(glogits), W_in, B, L, K, eps_tol, tau, ctx.seeds[0][0] & _MASK64,
+                     ctx.seeds[0][1] & _MASK64, ctx.row0, dt, stream_ptr(dev))
+            return glogits, None, None, None, None, None
         i_off = o_off = 0
         k = 0          # index into outs[1:] / gex
         st = stream_ptr(dev)

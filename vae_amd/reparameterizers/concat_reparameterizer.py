@@ -72,11 +72,20 @@ class ConcatReparameterizer(nn.Module):
             if kind == 'gauss':
                 logits_i = logits[:, i_off:i_off + 2 * n_out]
                 mu = logits_i[:, :n_out]
-                kl, means = outs[k + 1], outs[k + 2].to(logits.dtype)
+                kl, means = outs[k + 1], outs[k + 2]
                 g = LazyParams({'z': z_i, 'mu': mu})
                 g.set_lazy('logvar', lambda li=logits_i, n=n_out, e=spec[2]: li[:, n:] + e)   # on first read only
                 g._vae_amd_kl = (kl, mu)
-                g['mu_mean'], g['logvar_mean'] = means[0], means[1]
+                if means.numel():
+                    means = means.to(logits.dtype)
+                    g['mu_mean'], g['logvar_mean'] = means[0], means[1]
+                else:
+                    # the one-launch row kernel takes no grid-wide sums: the two diagnostics are the reference's own
+                    # ops (isotropic_gaussian.py:213-214), run if and when somebody reads them
+                    ms = child.mean_scale
+                    scale = (lambda t: torch.mean(t)) if ms is None else (lambda t, c=ms: torch.sum(t) * c)
+                    g.set_lazy('mu_mean', lambda m=mu, f=scale: f(m))
+                    g.set_lazy('logvar_mean', lambda gg=g, f=scale: f(gg['logvar']))
                 params = {'z': z_i, 'logits': logits_i, 'gaussian': g}
                 k, i_off = k + 3, i_off + 2 * n_out
             else:
