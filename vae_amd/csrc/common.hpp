@@ -597,6 +597,23 @@ __device__ __forceinline__ void philox_normal(uint64_t seed, uint64_t stream, ui
     }
   }
 }
+// the raw words behind philox_uniform (the same counters): out[i] is the word of element elem + i
+template <int V>
+__device__ __forceinline__ void philox_words(uint64_t seed, uint64_t stream, uint64_t elem, uint32_t (&out)[V]) {
+  if constexpr (V == 1) {
+    uint32_t w[4];
+    Philox::gen(seed, elem >> 2, stream, w);
+    out[0] = w[elem & 3];
+  } else {
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) {
+      uint32_t w[4];
+      Philox::gen(seed, (elem >> 2) + q, stream, w);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) out[4 * q + i] = w[i];
+    }
+  }
+}
 template <int V>
 __device__ __forceinline__ void philox_uniform(uint64_t seed, uint64_t stream, uint64_t elem, float (&out)[V]) {
   if constexpr (V == 1) {

@@ -22,7 +22,7 @@
 
 namespace vae {
 
-template <typename T, int V, int UG, int UK, bool INJ>
+template <typename T, int V, int UG, int UK, bool INJ, bool EXACT>
 __global__ __launch_bounds__(kBlock) void concat_gg_fwd_kernel(
     const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ noise, const T* __restrict__ unif,
     T* __restrict__ zcat, int64_t zc_stride, T* __restrict__ y_out, T* __restrict__ lq_out, T* __restrict__ kl,
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kBlock) void concat_gg_fwd_kernel(
     float klr = 0.f;
 #pragma unroll
     for (int k = 0; k < UG; ++k) {
-      const bool valid = sub + k * G < lvec;
+      const bool valid = EXACT || sub + k * G < lvec;   // EXACT: lvec == UG * G and kvec == UK * G, no masks
       const int j = valid ? sub + k * G : lvec - 1;
       if constexpr (!INJ) {
         if (training) philox_normal<V>(seed_g, offset_g, (uint64_t)(row0 + r) * (uint64_t)L + (uint64_t)j * V, e[k]);
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kBlock) void concat_gg_fwd_kernel(
     // ---- Gumbel child: y into the sample row in training, z_hard in eval (gumbel.py:336-341)
     T* yk = training ? zrow + L : (y_out ? y_out + r * K : nullptr);
     T* zh = training ? nullptr : zrow + L;
-    gumbel_row_fwd<T, V, UK, INJ>(l, u, yk, zh, lq_out ? lq_out + r * K : nullptr, live, nts, sub, G, kvec, tau, seed_k,
+    gumbel_row_fwd<T, V, UK, INJ, EXACT>(l, u, yk, zh, lq_out ? lq_out + r * K : nullptr, live, nts, sub, G, kvec, tau, seed_k,
                                   offset_k, (uint64_t)(row0 + r) * (uint64_t)K);
   }
 }
@@ -212,12 +212,18 @@ static int concat_fwd_dispatch(const void* logits, int64_t row_stride, const voi
   RowGeom g;
   int UG, UK;
   if (!vec || !concat_geom(B, L / VN, K / VN, kGridStream, &g, &UG, &UK)) return VAE_ERR_ARG;
-#define VAE_CONCAT_LAUNCH(INJ_)                                                                                       \
-  VAE_SWITCH_UG_UK(UG, UK, hipLaunchKernelGGL((concat_gg_fwd_kernel<T, VN, UG, UK, INJ_>), dim3(g.grid), dim3(kBlock), \
-                                              0, stream, (const T*)logits, row_stride, (const T*)noise, (const T*)unif, \
-                                              (T*)zcat, zc_stride, (T*)y, (T*)lq, (T*)kl, B, (int)L, (int)K, eps_tol,   \
-                                              tau, training, seed_g, offset_g, seed_k, offset_k, row0, g.G, g.tiles))
-  if (unif) { VAE_CONCAT_LAUNCH(true); } else { VAE_CONCAT_LAUNCH(false); }
+  const bool exact = L / VN == (int64_t)UG * g.G && K / VN == (int64_t)UK * g.G;
+#define VAE_CONCAT_LAUNCH(INJ_, EX_)                                                                                   \
+  VAE_SWITCH_UG_UK(UG, UK, hipLaunchKernelGGL((concat_gg_fwd_kernel<T, VN, UG, UK, INJ_, EX_>), dim3(g.grid),          \
+                                              dim3(kBlock), 0, stream, (const T*)logits, row_stride, (const T*)noise,  \
+                                              (const T*)unif, (T*)zcat, zc_stride, (T*)y, (T*)lq, (T*)kl, B, (int)L,   \
+                                              (int)K, eps_tol, tau, training, seed_g, offset_g, seed_k, offset_k, row0, \
+                                              g.G, g.tiles))
+  if (unif) {
+    if (exact) { VAE_CONCAT_LAUNCH(true, true); } else { VAE_CONCAT_LAUNCH(true, false); }
+  } else {
+    if (exact) { VAE_CONCAT_LAUNCH(false, true); } else { VAE_CONCAT_LAUNCH(false, false); }
+  }
 #undef VAE_CONCAT_LAUNCH
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }

@@ -13,10 +13,11 @@ constexpr float kNegInf = -3.402823466e+38f;
 // copies, masked here).  u: the injected uniforms when INJ, else scratch that receives the Philox draws keyed by the
 // element index elem0 + j*V.  y / zh / lq: this ROW's output pointers, each may be null (kernel-uniform); nothing is
 // stored unless `live`.  Every lane of the group (and, for G = kBlock, of the block) must call it.
+// EXACT: the caller guarantees nvec == U * G (every chunk of every lane is inside the row): no masks at all.
 // The arithmetic carries no branches: chunks past the row end are computed on their clamped copies and masked out
 // of the reductions and the stores (a branch per chunk cost ~60 scalar-register spills and their wait states in
 // the Concat row kernel, r03).
-template <typename T, int V, int U, bool INJ>
+template <typename T, int V, int U, bool INJ, bool EXACT = false>
 __device__ __forceinline__ void gumbel_row_fwd(const float (&l)[U][V], float (&u)[U][V], T* __restrict__ y,
                                                T* __restrict__ zh, T* __restrict__ lq, bool live, bool nts, int sub,
                                                int G, int nvec, float tau, uint64_t seed, uint64_t offset,
@@ -27,7 +28,7 @@ __device__ __forceinline__ void gumbel_row_fwd(const float (&l)[U][V], float (&u
   const bool want_soft = y != nullptr || zh != nullptr;
   bool valid[U];
 #pragma unroll
-  for (int k = 0; k < U; ++k) valid[k] = sub + k * G < nvec;
+  for (int k = 0; k < U; ++k) valid[k] = EXACT || sub + k * G < nvec;
 
   // ---- log_q_z = (l - max) - log(sum exp(l - max))
   float m1 = kNegInf, lse = 0.f;
@@ -61,46 +62,65 @@ __device__ __forceinline__ void gumbel_row_fwd(const float (&l)[U][V], float (&u
     return;
   }
 
-  // ---- x = (l + g)/tau + eps, g = -log(-log(U + eps) + eps): every op rounds on its own
+  // ---- x = (l + g)/tau + eps, g = -log(-log(U + eps) + eps)
   float x[U][V];
   float m2 = kNegInf;
-  const float itau = 1.0f / tau;
+  float s2 = 0.f;
+  if constexpr (INJ) {
+    // injected U: the reference's own roundings, every op on its own (accurate logs, an IEEE divide, ocml expf),
+    // through the tensor dtype wherever the reference holds a tensor
 #pragma unroll
-  for (int k = 0; k < U; ++k) {
-    const int j = valid[k] ? sub + k * G : nvec - 1;
-    if constexpr (!INJ) philox_uniform<V>(seed, offset, elem0 + (uint64_t)j * V, u[k]);
+    for (int k = 0; k < U; ++k) {
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-      // injected U: the reference's own roundings (accurate logs, an IEEE divide, ocml expf below).  In-kernel
-      // draws have nothing to be bit-compared with and that path is ALU-bound (Philox + three transcendentals per
-      // element against 8 bytes of traffic): bare v_log_f32 (arguments >= 1e-9: normal range), a multiply by
-      // 1/tau instead of the divide (~10 VALU ops), bare v_exp_f32 instead of expf (14).
-      float g, xi;
-      if constexpr (INJ) {
-        g = -logf(add_rn(u[k][i], kGumbelEps));
+      for (int i = 0; i < V; ++i) {
+        float g = -logf(add_rn(u[k][i], kGumbelEps));
         g = -logf(add_rn(g, kGumbelEps));
         g = to_f32(from_f32<T>(g));
-        xi = to_f32(from_f32<T>(div_rn(to_f32(from_f32<T>(add_rn(l[k][i], g))), tau)));
-      } else {
-        g = -fast_log(u[k][i] + kGumbelEps);
-        g = -fast_log(g + kGumbelEps);
-        g = to_f32(from_f32<T>(g));
-        xi = to_f32(from_f32<T>(mul_rn(to_f32(from_f32<T>(add_rn(l[k][i], g))), itau)));
+        const float xi = to_f32(from_f32<T>(div_rn(to_f32(from_f32<T>(add_rn(l[k][i], g))), tau)));
+        x[k][i] = to_f32(from_f32<T>(add_rn(xi, kGumbelEps)));
+        m2 = fmaxf(m2, valid[k] ? x[k][i] : kNegInf);
       }
-      x[k][i] = to_f32(from_f32<T>(add_rn(xi, kGumbelEps)));
-      m2 = fmaxf(m2, valid[k] ? x[k][i] : kNegInf);
     }
+    m2 = row_max(m2, G);
+#pragma unroll
+    for (int k = 0; k < U; ++k)
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        x[k][i] = expf(sub_rn(x[k][i], m2));
+        s2 += valid[k] ? x[k][i] : 0.f;
+      }
+  } else {
+    // In-kernel draws have nothing to be bit-compared with, and this path is VALU-bound (r03, rocprofv3: the Concat row
+    // kernel issues ~700 VALU instructions per wave for 12 elements per lane; Philox is a third of them).  The same
+    // formula in fp32 with the constants folded, in the log2 domain: with t = log2,
+    //   u + eps       = fma(word >> 8, 2^-24, 2^-25 + eps)
+    //   -ln(u+eps)+eps = fma(-ln2, t(u + eps), eps)                       =: g1
+    //   log2(e) * x   = fma(t(g1), -ln2 * c, fma(l, c, eps * log2(e))),   c = log2(e) / tau
+    // and y = exp2(that - rowmax) / sum: 10 VALU + 3 transcendental instructions per element.
+    const float c = kLog2e / tau;
+    const float c0 = kGumbelEps * kLog2e, c2 = -kLn2 * c;
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int j = valid[k] ? sub + k * G : nvec - 1;
+      uint32_t w[V];
+      philox_words<V>(seed, offset, elem0 + (uint64_t)j * V, w);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const float ue = __builtin_fmaf((float)(w[i] >> 8), 1.0f / 16777216.0f, 0.5f / 16777216.0f + kGumbelEps);
+        const float g1 = __builtin_fmaf(-kLn2, log2_raw(ue), kGumbelEps);
+        x[k][i] = __builtin_fmaf(log2_raw(g1), c2, __builtin_fmaf(l[k][i], c, c0));
+        m2 = fmaxf(m2, valid[k] ? x[k][i] : kNegInf);
+      }
+    }
+    m2 = row_max(m2, G);
+#pragma unroll
+    for (int k = 0; k < U; ++k)
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        x[k][i] = __builtin_amdgcn_exp2f(x[k][i] - m2);
+        s2 += valid[k] ? x[k][i] : 0.f;
+      }
   }
-  m2 = row_max(m2, G);
-  float s2 = 0.f;
-#pragma unroll
-  for (int k = 0; k < U; ++k)
-#pragma unroll
-    for (int i = 0; i < V; ++i) {
-      if constexpr (INJ) x[k][i] = expf(sub_rn(x[k][i], m2));
-      else x[k][i] = fast_exp(sub_rn(x[k][i], m2));
-      s2 += valid[k] ? x[k][i] : 0.f;
-    }
   s2 = row_sum(s2, G);
   const float rinv = div_rn(1.0f, s2);  // ATen's CPU softmax multiplies by the reciprocal
   float ymax = 0.f;
