@@ -313,6 +313,18 @@ int main(int argc, char** argv) {
   run_rows<2, 1, true, false>("rows 2R1W 800 px", pool, nvec, 200, it);
   run_rows<3, 1, true, false>("rows 3R1W 512", pool, nvec, 128, it);
   run_rows<3, 1, true, true>("rows 3R1W 512 nt stores", pool, nvec, 128, it);
+  if (argc > 3 && argv[3][0] == 'w') {   // write-heavy mixes (r03): the long-row NLL backward is 3R2W (mb = 402, nbuf = 10)
+    run<3, 2, 4, true, true>("3R2W nt stores", pool, nvec, 0, it);
+    run<3, 2, 4, true, false>("3R2W plain stores", pool, nvec, 0, it);
+    run<3, 2, 2, true, true>("3R2W nt stores U2", pool, nvec, 0, it);
+    run<3, 2, 1, true, true>("3R2W nt stores U1", pool, nvec, 0, it);
+    run<3, 1, 4, true, true>("3R1W nt stores", pool, nvec, 0, it);
+    run<3, 0, 4, true, true>("3R0W", pool, nvec, 0, it);
+    run<1, 2, 4, true, true>("1R2W nt stores", pool, nvec, 0, it);
+    run<2, 2, 4, true, true>("2R2W nt stores", pool, nvec, 0, it);
+    run<4, 2, 4, true, true>("4R2W nt stores", pool, nvec, 0, it);
+    return 0;
+  }
   if (argc > 3 && argv[3][0] == 's') {   // short rows: mb = 103 for the bf16 C2 streams
     run_short<64, 1, 2, true>("short G64 1 row U2 (library)", pool, nvec, 98, it);
     run_short<64, 2, 2, true>("short G64 2 rows U2", pool, nvec, 98, it);

@@ -32,7 +32,7 @@ int vae_rng_reset(vae_stream_t stream) {
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 // counters + group partials + one partial per block x up to 8 scalars (common.hpp, grid_reduce)
-size_t vae_workspace_bytes(void) { return vae::kWorkspaceFloats * sizeof(float); }
+size_t vae_workspace_bytes(void) { return vae::kWorkspaceFloatsFull * sizeof(float); }
 
 int vae_tuning_set(const char* name, int64_t value) {
   if (!name) return VAE_ERR_ARG;

@@ -372,6 +372,11 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 constexpr int kReduceGridMax = 2048;
 constexpr int kTicketFan = 32;
 constexpr size_t kWorkspaceFloats = 1024 + (size_t)kReduceGridMax * 8;
+// Behind the counters and block partials a caller's workspace holds kRowPartFloats more floats: the per-chunk row
+// sums of the one-pass NLL on long rows (csrc/elbo.hip: a row cut into chunks of one block each).  The library's
+// own static scratch (vae_nll_elbo_fused_static) has no such area and keeps the block-per-row loop.
+constexpr size_t kRowPartFloats = (size_t)1 << 20;
+constexpr size_t kWorkspaceFloatsFull = kWorkspaceFloats + kRowPartFloats;
 
 __device__ __forceinline__ void shared_store(float* p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -102,7 +102,7 @@ template <typename T, int V, int NLL, int U, typename Src>
 __global__ __launch_bounds__(kBlock) void nll_elbo_bwd_kernel(
     Src src, const T* __restrict__ gnll, const T* __restrict__ gloss, const T* __restrict__ gelbo,
     const float* __restrict__ gmeans, T* __restrict__ gkld, T* __restrict__ gadd, T* __restrict__ gmi,
-    int64_t rows_total, int D, float kl_beta, float inv_count, int G, int64_t tiles) {
+    int64_t rows_total, int D, float kl_beta, float inv_count, int G, int64_t tiles, int cpr) {
   const int rpb = kBlock / G;
   const bool nts = nt_stores(rows_total * D * (int64_t)sizeof(T));
   const int sub = threadIdx.x % G;
@@ -113,7 +113,14 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_bwd_kernel(
 #pragma unroll
   for (int k = 0; k < 6; ++k) gm[k] = gmeans ? gmeans[k] * inv_count : 0.f;
 
-  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+  // cpr > 1 (block-per-row geometry, long rows): a row is cut into cpr chunks of G * U vectors and every block takes
+  // ONE chunk -- the backward needs no row sum, so nothing ties the chunks of a row together.  One pass of loads,
+  // arithmetic and stores per block instead of a loop whose every iteration first waits for the acknowledgement of
+  // the previous iteration's stores (vmcnt retires in order): 3x64x64 rows 5.33 -> TB/s of the flat 3R2W stream
+  // (scripts/membench 402 10 w: 6.06 TB/s).
+  for (int64_t tc = blockIdx.x; tc < tiles * cpr; tc += gridDim.x) {
+    const int64_t t = cpr == 1 ? tc : tc / cpr;
+    const int chunk = cpr == 1 ? 0 : (int)(tc - t * cpr);
     int64_t row;
     const T *xr, *rr;
     T* gr;
@@ -121,12 +128,13 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_bwd_kernel(
     const float gl = (gloss ? to_f32(gloss[row]) : 0.f) + gm[0];
     const float ge = (gelbo ? to_f32(gelbo[row]) : 0.f) + gm[1];
     const float c = (gnll ? to_f32(gnll[row]) : 0.f) + gl + ge + gm[2];
-    if (sub == 0) {
+    if (sub == 0 && chunk == 0) {
       if (gkld) gkld[row] = from_f32<T>(src.beta(t, kl_beta) * gl + ge + gm[3]);
       if (gadd) gadd[row] = from_f32<T>(gl + gm[4]);
       if (gmi) gmi[row] = from_f32<T>(gm[5] - gl);
     }
-    for (int j0 = sub; j0 < nvec; j0 += G * U) {
+    const int jend = cpr == 1 ? nvec : min(nvec, (chunk + 1) * G * U);
+    for (int j0 = sub + chunk * G * U; j0 < jend; j0 += G * U) {
       float xv[U][V], a[U][V], b[U][V];
       load_chunk<T, V, U, kNtNllBwd>(xr, j0, G, nvec, xv);
       load_chunk<T, V, U, kNtNllBwd>(rr, j0, G, nvec, a);
@@ -287,6 +295,85 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_fused_kernel(
   }
 }
 
+// The same for long rows (block-per-row geometry), one CHUNK of kBlock * U vectors per block: a block-per-row loop
+// waits, at every iteration, for the acknowledgement of the previous iteration's gradient stores before its next
+// loads return (loads and stores retire through one in-order counter), and measured 5.2-5.3 TB/s on 3x64x64 rows
+// where the flat 3R2W stream runs 6.06 (scripts/membench 402 10 w).  Here every block makes one pass -- loads,
+// arithmetic, stores -- and leaves the sum of its chunk in parts[row * cpr + chunk]; nll_rows_from_parts_kernel adds
+// a row's chunks in chunk order (deterministic) and finishes the row.
+template <typename T, int V, int NLL, int U>
+__global__ __launch_bounds__(kBlock) void nll_elbo_fused_chunk_kernel(
+    const T* __restrict__ x, const T* __restrict__ recon, T* __restrict__ grecon, float* __restrict__ parts,
+    float cscale, int64_t B, int D, int cpr) {
+  const bool nts = nt_stores((int64_t)B * D * (int64_t)sizeof(T));
+  const int nvec = D / V;
+  const int64_t rstride = (NLL == VAE_NLL_BERNOULLI) ? (int64_t)D : 2 * (int64_t)D;
+  for (int64_t tc = blockIdx.x; tc < B * cpr; tc += gridDim.x) {
+    const int64_t row = tc / cpr;
+    const int chunk = (int)(tc - row * cpr);
+    const T* xr = x + row * D;
+    const T* rr = recon + row * rstride;
+    T* gr = grecon + row * rstride;
+    const int j0 = threadIdx.x + chunk * kBlock * U;
+    float s = 0.f;
+    float xv[U][V], a[U][V], b[U][V];
+    load_chunk<T, V, U, kNtNllFwd>(xr, j0, kBlock, nvec, xv);
+    load_chunk<T, V, U, kNtNllFwd>(rr, j0, kBlock, nvec, a);
+    if constexpr (NLL != VAE_NLL_BERNOULLI) load_chunk<T, V, U, kNtNllFwd>(rr + D, j0, kBlock, nvec, b);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * kBlock;
+      if (j < nvec) {
+        float ga[V], gb[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          if constexpr (NLL == VAE_NLL_BERNOULLI) {
+            const float l = a[u][i];
+            const float e = fast_exp(-fabsf(l));
+            const float r = fast_rcp(1.0f + e);
+            s += fmaxf(l, 0.0f) - l * xv[u][i] + fast_log(1.0f + e);
+            const float er = e * r;
+            ga[i] = cscale * (l >= 0.0f ? (1.0f - xv[u][i]) - er : er - xv[u][i]);
+          }
+          if constexpr (NLL == VAE_NLL_GAUSSIAN) {
+            s += nll_gauss(xv[u][i], a[u][i], b[u][i]);
+            nll_gauss_grad(xv[u][i], a[u][i], b[u][i], ga[i], gb[i]);
+            ga[i] *= cscale; gb[i] *= cscale;
+          }
+          if constexpr (NLL == VAE_NLL_DISC_LOGISTIC) {
+            s += nll_dlog(xv[u][i], a[u][i], b[u][i]);
+            nll_dlog_grad(xv[u][i], a[u][i], b[u][i], ga[i], gb[i]);
+            ga[i] *= cscale; gb[i] *= cscale;
+          }
+        }
+        store_vec<T, V>(nts, gr + (int64_t)j * V, ga);
+        if constexpr (NLL != VAE_NLL_BERNOULLI) store_vec<T, V>(nts, gr + D + (int64_t)j * V, gb);
+      }
+    }
+    s = row_sum(s, kBlock);
+    if (threadIdx.x == 0) parts[tc] = s;
+  }
+}
+
+// nll / loss / elbo [B] from the per-chunk sums: one thread per row, chunks added in chunk order.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void nll_rows_from_parts_kernel(
+    const float* __restrict__ parts, int cpr, const T* __restrict__ kld, const T* __restrict__ add,
+    const T* __restrict__ mi, T* __restrict__ nll_out, T* __restrict__ loss, T* __restrict__ elbo, int64_t B,
+    float kl_beta) {
+  for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < B; row += (int64_t)gridDim.x * kBlock) {
+    float s = parts[row * cpr];
+    for (int c = 1; c < cpr; ++c) s += parts[row * cpr + c];
+    const float k = kld ? to_f32(kld[row]) : 0.f;
+    const float ad = add ? to_f32(add[row]) : 0.f;
+    const float m = mi ? to_f32(mi[row]) : 0.f;
+    const float n = to_f32(from_f32<T>(s));
+    nll_out[row] = from_f32<T>(n);
+    loss[row] = from_f32<T>((n + ad + kl_beta * k) - m);
+    elbo[row] = from_f32<T>(n + k);
+  }
+}
+
 // buf *= (gmeans[0] + gmeans[1] + gmeans[2]) unless that sum is exactly 1 (then no memory is touched):
 // the stored d(loss_mean)/d(recon) becomes the gradient for any upstream weights on loss_mean, elbo_mean, nll_mean.
 template <typename T, int V>
@@ -336,10 +423,27 @@ __global__ __launch_bounds__(kBlock) void nll_fused_backward_kernel(T* __restric
 template <typename T, int NLL>
 static int nll_fused_dispatch(const void* x, const void* recon, const void* kld, const void* add, const void* mi,
                               void* nll, void* loss, void* elbo, float* means, float* workspace, void* grecon,
-                              float cscale, int64_t B, int64_t D, float kl_beta, float inv_count, hipStream_t stream) {
+                              float cscale, int64_t B, int64_t D, float kl_beta, float inv_count, hipStream_t stream,
+                              bool has_row_parts) {
   constexpr int VN = VecOf<T>::n;
   const bool vec = (D % VN == 0) && aligned16(x) && aligned16(recon) && aligned16(grecon);
   const RowGeom g = nll_geom(B, vec ? D / VN : D, kGridStream, true);
+  const int64_t nvec = vec ? D / VN : D;
+  const int64_t cpr = (nvec + (int64_t)kBlock * 4 - 1) / ((int64_t)kBlock * 4);
+  if (vec && has_row_parts && g.G == kBlock && cpr > 1 && B * cpr <= (int64_t)kRowPartFloats && !knobs().maxgrid) {
+    // long rows: one chunk per block, per-chunk sums behind the workspace's counters and block partials
+    float* parts = workspace + kWorkspaceFloats;
+    const int64_t work = B * cpr;
+    const int grid = (int)(work < kGridStream ? work : kGridStream);
+    hipLaunchKernelGGL((nll_elbo_fused_chunk_kernel<T, VN, NLL, 4>), dim3(grid), dim3(kBlock), 0, stream, (const T*)x,
+                       (const T*)recon, (T*)grecon, parts, cscale, B, (int)D, (int)cpr);
+    const int64_t rb = (B + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL((nll_rows_from_parts_kernel<T>), dim3((int)(rb < 1024 ? rb : 1024)), dim3(kBlock), 0, stream,
+                       parts, (int)cpr, (const T*)kld, (const T*)add, (const T*)mi, (T*)nll, (T*)loss, (T*)elbo, B,
+                       kl_beta);
+    launch_rows_means<T>(loss, elbo, nll, kld, add, mi, workspace, inv_count, means, B, stream);
+    return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+  }
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_fused_kernel<T, VN, NLL, U>), dim3(g.grid), dim3(kBlock), 0, stream,
                                          (const T*)x, (const T*)recon, (const T*)kld, (const T*)add, (const T*)mi,
@@ -359,17 +463,17 @@ template <typename T>
 static int nll_fused_type(int nll_type, const void* x, const void* recon, const void* kld, const void* add,
                           const void* mi, void* nll, void* loss, void* elbo, float* means, float* workspace,
                           void* grecon, float cscale, int64_t B, int64_t D, float kl_beta, float inv_count,
-                          hipStream_t st) {
+                          hipStream_t st, bool has_row_parts) {
   switch (nll_type) {
     case VAE_NLL_BERNOULLI:
       return nll_fused_dispatch<T, VAE_NLL_BERNOULLI>(x, recon, kld, add, mi, nll, loss, elbo, means, workspace, grecon,
-                                                      cscale, B, D, kl_beta, inv_count, st);
+                                                      cscale, B, D, kl_beta, inv_count, st, has_row_parts);
     case VAE_NLL_GAUSSIAN:
       return nll_fused_dispatch<T, VAE_NLL_GAUSSIAN>(x, recon, kld, add, mi, nll, loss, elbo, means, workspace, grecon,
-                                                     cscale, B, D, kl_beta, inv_count, st);
+                                                     cscale, B, D, kl_beta, inv_count, st, has_row_parts);
     case VAE_NLL_DISC_LOGISTIC:
       return nll_fused_dispatch<T, VAE_NLL_DISC_LOGISTIC>(x, recon, kld, add, mi, nll, loss, elbo, means, workspace,
-                                                          grecon, cscale, B, D, kl_beta, inv_count, st);
+                                                          grecon, cscale, B, D, kl_beta, inv_count, st, has_row_parts);
   }
   return VAE_ERR_ARG;
 }
@@ -397,15 +501,19 @@ static void nll_bwd_launch(const Src& src, bool vec, const RowGeom& g, int64_t t
                            const void* gnll, const void* gloss, const void* gelbo, const float* gmeans, void* gkld,
                            void* gadd, void* gmi, int64_t D, float kl_beta, float inv_count, hipStream_t stream) {
   constexpr int VN = VecOf<T>::n;
-  const int grid = (int)(tiles < kGridStream ? tiles : kGridStream);
+  // block-per-row geometry: one chunk of G * U vectors per block (see the kernel)
+  const int64_t nvec = vec ? D / VN : D;
+  const int cpr = (g.G == kBlock && !knobs().maxgrid) ? (int)((nvec + (int64_t)kBlock * g.U - 1) / ((int64_t)kBlock * g.U)) : 1;
+  const int64_t work = tiles * cpr;
+  const int grid = (int)(work < kGridStream ? work : kGridStream);
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_bwd_kernel<T, VN, NLL, U, Src>), dim3(grid), dim3(kBlock), 0, stream,
                                          src, (const T*)gnll, (const T*)gloss, (const T*)gelbo, gmeans, (T*)gkld,
-                                         (T*)gadd, (T*)gmi, rows_total, (int)D, kl_beta, inv_count, g.G, tiles));
+                                         (T*)gadd, (T*)gmi, rows_total, (int)D, kl_beta, inv_count, g.G, tiles, cpr));
   } else {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((nll_elbo_bwd_kernel<T, 1, NLL, U, Src>), dim3(grid), dim3(kBlock), 0, stream,
                                          src, (const T*)gnll, (const T*)gloss, (const T*)gelbo, gmeans, (T*)gkld,
-                                         (T*)gadd, (T*)gmi, rows_total, (int)D, kl_beta, inv_count, g.G, tiles));
+                                         (T*)gadd, (T*)gmi, rows_total, (int)D, kl_beta, inv_count, g.G, tiles, cpr));
   }
 }
 
@@ -652,9 +760,10 @@ int vae_nll_steps_elbo_bwd(const void* const* xs, const void* const* recons, voi
   return VAE_ERR_ARG;
 }
 
-int vae_nll_elbo_fused(const void* x, const void* recon, int nll_type, const void* kld, const void* add, const void* mi,
-                       float kl_beta, float inv_count, float grad_scale, void* nll, void* loss, void* elbo, float* means,
-                       float* workspace, void* grecon, int64_t B, int64_t D, int dtype, vae_stream_t stream) {
+static int nll_elbo_fused_impl(const void* x, const void* recon, int nll_type, const void* kld, const void* add,
+                               const void* mi, float kl_beta, float inv_count, float grad_scale, void* nll, void* loss,
+                               void* elbo, float* means, float* workspace, void* grecon, int64_t B, int64_t D, int dtype,
+                               vae_stream_t stream, bool has_row_parts) {
   if (B < 0 || D <= 0 || D > VAE_MAX_ROW) return VAE_ERR_ARG;
   if (B == 0) return VAE_OK;
   if (!x || !recon || !nll || !loss || !elbo || !means || !workspace || !grecon) return VAE_ERR_ARG;
@@ -662,14 +771,21 @@ int vae_nll_elbo_fused(const void* x, const void* recon, int nll_type, const voi
   const float cscale = inv_count * grad_scale;
   if (dtype == VAE_F32)
     return nll_fused_type<float>(nll_type, x, recon, kld, add, mi, nll, loss, elbo, means, workspace, grecon, cscale,
-                                 B, D, kl_beta, inv_count, st);
+                                 B, D, kl_beta, inv_count, st, has_row_parts);
   if (dtype == VAE_BF16)
     return nll_fused_type<bf16_t>(nll_type, x, recon, kld, add, mi, nll, loss, elbo, means, workspace, grecon, cscale,
-                                  B, D, kl_beta, inv_count, st);
+                                  B, D, kl_beta, inv_count, st, has_row_parts);
   if (dtype == VAE_F16)
     return nll_fused_type<f16_t>(nll_type, x, recon, kld, add, mi, nll, loss, elbo, means, workspace, grecon, cscale,
-                                  B, D, kl_beta, inv_count, st);
+                                  B, D, kl_beta, inv_count, st, has_row_parts);
   return VAE_ERR_ARG;
+}
+
+int vae_nll_elbo_fused(const void* x, const void* recon, int nll_type, const void* kld, const void* add, const void* mi,
+                       float kl_beta, float inv_count, float grad_scale, void* nll, void* loss, void* elbo, float* means,
+                       float* workspace, void* grecon, int64_t B, int64_t D, int dtype, vae_stream_t stream) {
+  return nll_elbo_fused_impl(x, recon, nll_type, kld, add, mi, kl_beta, inv_count, grad_scale, nll, loss, elbo, means,
+                             workspace, grecon, B, D, dtype, stream, true);
 }
 
 int vae_nll_elbo_fused_static(const void* x, const void* recon, int nll_type, const void* kld, const void* add,
@@ -684,8 +800,9 @@ int vae_nll_elbo_fused_static(const void* x, const void* recon, int nll_type, co
   // The array keeps the last call's contents: the arrival counters must read zero when the closing launch starts
   // (a completed call leaves them at zero; one that was cut short need not).  The saw-a-NaN word behind them stays.
   if (hipMemsetAsync(ws, 0, vae::kWsNanFlag * sizeof(float), (hipStream_t)stream) != hipSuccess) return VAE_ERR_LAUNCH;
-  return vae_nll_elbo_fused(x, recon, nll_type, kld, add, mi, kl_beta, inv_count, grad_scale, nll, loss, elbo, means,
-                            ws, grecon, B, D, dtype, stream);
+  // the library's own array has no per-chunk area: long rows keep the block-per-row loop here
+  return nll_elbo_fused_impl(x, recon, nll_type, kld, add, mi, kl_beta, inv_count, grad_scale, nll, loss, elbo, means,
+                             ws, grecon, B, D, dtype, stream, false);
 }
 
 int vae_nan_flag(float* workspace, int clear, uint32_t* flags_out, vae_stream_t stream) {

@@ -141,9 +141,9 @@ inline RowGeom nll_geom(int64_t B, int64_t vecs_per_row, int64_t max_grid, bool 
                         bool loads_only = false) {
   RowGeom g = row_geom(B, vecs_per_row, max_grid);
   if (loads_only && g.G == 64 && vecs_per_row <= 128) regroup(g, B, 32, 4, max_grid);
-  if (vecs_per_row >= 1024 && (long_rows_always || g.tiles < 4 * 256)) {
+  if (vecs_per_row >= 1024 && (long_rows_always || g.tiles < 4 * 256) && !knobs().G) {
     g.G = kBlock;
-    g.U = 4;
+    g.U = knobs().U ? knobs().U : 4;
     g.rows_per_block = 1;
     g.tiles = B;
     g.grid = (int)(g.tiles < max_grid ? g.tiles : max_grid);
