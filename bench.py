@@ -21,8 +21,12 @@ project); their outputs (encoder logits, decoder logits) and the decoder's gradi
 synthetic tensors.  Every kernel goes through the C ABI (libvae_amd.so); HIP events around every
 launch of the timed steps give the per-kernel durations behind `roofline`.
 
-The batch shards by rows with no data-path collective except the scalar all-reduce (weak scaling:
-per-GPU batch fixed).  Prints ONE JSON line on rank 0.
+The batch shards by rows with no data-path collective except the scalar all-reduce.  `value` is the WEAK-scaling
+figure (B = 65536 per GPU); `strong_scaling` in the same line is the other reading of "the batch is sharded across the
+8 GPUs": a GLOBAL batch of 65536, B / N rows per GPU, the four launches replayed from one HIP graph (at 8192 rows per
+GPU the step is launch-bound otherwise) with the scalar all-reduce beside it.  `configs` holds BASELINE.json's other
+configurations (C3 Concat, C4 Gaussian->Flow + discretized logistic, C5 VRNN T = 64) through the module classes, timed
+by scripts/bench_configs.py's functions.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -53,7 +57,7 @@ def algorithmic_bytes(B, philox=False):
     }
 
 
-def cpu_baseline(seconds=12.0):
+def cpu_baseline(seconds=10.0, L=L, label='configs[1] shapes'):
     """The oracle's unfused op sequence (the reference's CPU path restated) on the host cores."""
     from oracle import cpu_ref as O
     threads = torch.get_num_threads()
@@ -72,8 +76,33 @@ def cpu_baseline(seconds=12.0):
         if dt > seconds:
             break
     return {'value': Bc * n / dt, 'unit': 'samples/s', 'cores': threads, 'kind': 'port',
-            'sample': '%d fwd+bwd ELBO steps of B=%d, L=%d, 1x28x28 Bernoulli, fp32, oracle/cpu_ref.elbo_step '
-                      '(torch CPU ops in the reference op order), %.1f s' % (n, Bc, L, dt)}
+            'sample': '%s: %d fwd+bwd ELBO steps of B=%d, L=%d, 1x28x28 Bernoulli, fp32, oracle/cpu_ref.elbo_step '
+                      '(torch CPU ops in the reference op order), %.1f s' % (label, n, Bc, L, dt)}
+
+
+def configs_block():
+    """BASELINE.json's other configurations through the drop-in classes, timed by the functions of
+    scripts/bench_configs.py (each launch sequence behind a 512 MiB fill of another buffer, median of 9: cache-cold,
+    what a training step sees; profiles/r03_configs.txt is the same functions run from that script)."""
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    import bench_configs as bc
+    bc.QUIET = True
+    bc.rows.clear()
+    bc.concat_module(65536, 128, 256)          # C3
+    bc.c4_module(8192)                         # C4
+    bc.vrnn_sequence(64, 4096, 128)            # C5
+    keep = ('concat step (eager)', 'concat step (HIP graph)', 'c4 latent chain (module)', 'c4 loss (module)',
+            'vrnn sequence (eager)', 'vrnn sequence (HIP graph)')
+    tag = {'concat': 'configs[2] C3', 'c4': 'configs[3] C4', 'vrnn': 'configs[4] C5'}
+    out = []
+    for r in bc.rows:
+        if r['kernel'] in keep:
+            out.append({'config': tag[r['kernel'].split()[0]], 'what': r['kernel'], 'shape': r['config'],
+                        'ms_per_step': r['ms'], 'algorithmic_bytes': int(r['algorithmic_MB'] * 1e6),
+                        'achieved_GBs': r['GBs'], 'frac': r['frac_of_8TBs']})
+    bc.rows.clear()
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -85,6 +114,7 @@ def main():
                     help='timed regions of --steps steps each (every one fenced on both sides); value = the median one')
     ap.add_argument('--batch', type=int, default=B_PER_GPU, help='samples per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help="skip the `configs` block (BASELINE.json's C3 / C4 / C5)")
     ap.add_argument('--main-only', action='store_true',
                     help='only the timed region (profiling runs: no Philox variant, no module path, no CPU leg)')
     ap.add_argument('--two-pass', action='store_true', help='separate NLL forward and backward kernels')
@@ -273,8 +303,22 @@ def main():
     # all-reduce of the loss scalars (vae_amd.dist.globalize_loss) and ONE flat all-reduce of the network gradients
     # (vae_amd.dist.FlatGradients; RCCL over xGMI under the default backend).  Reported beside the hot-path figure.
     whole_model = None
+    strong = None
     if not args.main_only:
         whole_model = whole_model_leg(dev, x.view(B, C, H, W), B, world, fence, all_reduce if dist is not None else None)
+        whole_model['scaling'] = 'weak'
+        # the strong-scaling leg: global batch 65536 over the ranks (at one GPU it is the same batch as the weak leg,
+        # replayed from a graph)
+        if B == B_PER_GPU:
+            strong = strong_leg(dev, rank, world, dist, backend, fence, all_reduce, args.steps, args.warmup, args.repeats,
+                                use_graph=os.environ.get('BENCH_STRONG_GRAPH', '1') != '0')
+            if world > 1:
+                _, Bs = __import__('vae_amd.dist', fromlist=['shard_rows']).shard_rows(B_PER_GPU, rank, world)
+                wm = whole_model_leg(dev, x.view(B, C, H, W)[:Bs], Bs, world, fence, all_reduce, global_batch=B_PER_GPU)
+                wm['scaling'] = 'strong'
+                strong['whole_model'] = wm
+            else:
+                strong['whole_model'] = 'one GPU: identical to whole_model'
 
     # the production form of the same step (the module classes' default): eps drawn inside the kernels from
     # Philox4x32-10 instead of read from HBM -- reported beside the main figure, never as `value`
@@ -460,22 +504,118 @@ def main():
                          'frac': round(total_bytes / (ksum * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             'loss_mean': sanity,
             'whole_model': whole_model,
+            'strong_scaling': strong,
             'module_path': module_path,
             'philox_variant': philox_variant,
             'bf16_variant': bf16_variant,
             'stock_torch_same_gpu': stock_torch,
             'graph_replay': graph_replay,
         }
+        if world == 1 and not args.main_only and not args.no_configs:
+            out['configs'] = configs_block()
         if world == 1 and not args.no_cpu_baseline and not args.main_only:
             out['cpu_baseline'] = cpu_baseline()
+            # BASELINE.json configs[0], the designated CPU configuration: latent 32
+            out['cpu_baseline_c1'] = cpu_baseline(seconds=6.0, L=32, label='configs[0] shapes')
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def whole_model_leg(dev, x_img, B, world, fence, all_reduce_max, steps=10, warmup=3):
+def strong_leg(dev, rank, world, dist, backend, fence, all_reduce, steps, warmup, repeats, use_graph=True):
+    """The strong-scaling reading of north_star ("the batch is sharded across the 8 GPUs"): a GLOBAL batch of
+    B_PER_GPU rows, this rank's contiguous shard of it (vae_amd.dist.shard_rows), the same four launches.  At 8192
+    rows per GPU the launches are 5-20 us each and the step is launch-bound from Python, so the step is recorded once
+    into a HIP graph and replayed; the 8-float all-reduce stays outside the graph, on RCCL's stream, on a COPY of the
+    scalars (the next replay rewrites the originals while the collective may still be reading).
+    Stream order per step: replay (launch stream) -> wait for the previous step's collective (launch stream waits, no
+    host block) -> copy of the 8 scalars (launch stream) -> all-reduce enqueued: ProcessGroupNCCL makes its own stream
+    wait for the launch stream's work so far, i.e. for that copy."""
+    from vae_amd import _lib
+    from vae_amd import dist as vdist
+    from vae_amd._lib import call, ptr
+    row0, B = vdist.shard_rows(B_PER_GPU, rank, world)
+    gen = torch.Generator(device=dev).manual_seed(4321 + rank)
+    f32 = dict(dtype=torch.float32, device=dev)
+    logits = torch.randn(B, 2 * L, generator=gen, **f32)
+    noise = torch.randn(B, L, generator=gen, **f32)
+    x = (torch.rand(B, D, generator=gen, **f32) < 0.13).float()
+    recon = torch.randn(B, D, generator=gen, **f32)
+    gz = torch.randn(B, L, generator=gen, **f32) * (1.0 / B_PER_GPU)
+    z, kl, nll, loss, elbo = (torch.empty(B, L, **f32), torch.empty(B, **f32), torch.empty(B, **f32),
+                              torch.empty(B, **f32), torch.empty(B, **f32))
+    scalars, scal_copy, gmeans = torch.zeros(8, **f32), torch.zeros(8, **f32), torch.zeros(6, **f32)
+    gmeans[0] = 1.0
+    grecon, gkld, glogits = torch.empty(B, D, **f32), torch.empty(B, **f32), torch.empty(B, 2 * L, **f32)
+    inv_count, mean_scale = 1.0 / B_PER_GPU, 1.0 / (B_PER_GPU * L)
+    pmeans = ctypes_off(scalars, 6)
+
+    def launches(ws, st):
+        call('vae_gauss_reparam_kl_fwd', ptr(logits), 2 * L, ptr(noise), ptr(z), L, None, ptr(kl), pmeans, ptr(ws), B, L,
+             1e-6, mean_scale, 1, 1234, 1, row0, 0, st)
+        call('vae_nll_elbo_fused', ptr(x), ptr(recon), 0, ptr(kl), None, None, 1.0, inv_count, 1.0, ptr(nll), ptr(loss),
+             ptr(elbo), ptr(scalars), ptr(ws), ptr(grecon), B, D, 0, st)
+        call('vae_nll_fused_backward', ptr(grecon), B * D, ptr(gmeans), 1.0, inv_count, ptr(gkld), None, None, B, 0, st)
+        call('vae_gauss_reparam_kl_bwd', ptr(logits), 2 * L, ptr(noise), ptr(gz), L, None, ptr(gkld), None, ptr(glogits),
+             2 * L, B, L, 1e-6, mean_scale, 1, 1234, 1, row0, 0, st)
+
+    graph = None
+    if use_graph:
+        side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side):
+            launches(_lib.workspace(dev), _lib.stream_ptr(dev))      # the side stream's workspace, outside the capture
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            launches(_lib.workspace(dev), _lib.stream_ptr(dev))
+    overlap = dist is not None and backend == 'nccl'
+    pending = [None]
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            launches(_lib.workspace(dev), _lib.stream_ptr(dev))
+        if dist is not None:
+            if pending[0] is not None:
+                pending[0].wait()
+                pending[0] = None
+            scal_copy.copy_(scalars)
+            if overlap:
+                pending[0] = dist.all_reduce(scal_copy, op=dist.ReduceOp.SUM, async_op=True)
+            else:
+                all_reduce(scal_copy)
+
+    for _ in range(warmup):
+        step()
+    region_ms = []
+    for _ in range(max(1, repeats)):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
+        fence()
+        dtr = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dtr], dtype=torch.float64, device=dev)
+            all_reduce(t, op=dist.ReduceOp.MAX)
+            dtr = float(t.item())
+        region_ms.append(dtr * 1e3)
+    dt = sorted(region_ms)[len(region_ms) // 2] * 1e-3
+    loss_mean = float((scal_copy if dist is not None else scalars)[0].item())
+    return {'scaling': 'strong', 'global_batch': B_PER_GPU, 'rows_this_rank': B, 'value': B_PER_GPU * steps / dt,
+            'unit': 'samples/s', 'ms_per_step': dt / steps * 1e3, 'ms_per_step_min': min(region_ms) / steps,
+            'ms_per_step_max': max(region_ms) / steps, 'launches': 'one HIP graph replay per step' if graph is not None
+            else 'eager', 'loss_mean': loss_mean}
+
+
+def whole_model_leg(dev, x_img, B, world, fence, all_reduce_max, steps=10, warmup=3, global_batch=None):
     import torch.distributed as tdist
+    global_batch = B * world if global_batch is None else global_batch
     sys.path.insert(0, os.path.join(ROOT, 'examples'))
     from train_simple_vae import SimpleVAE
     from vae_amd import dist as vdist
@@ -484,7 +624,7 @@ def whole_model_leg(dev, x_img, B, world, fence, all_reduce_max, steps=10, warmu
     torch.manual_seed(0)                       # the same initial weights on every rank
     model = SimpleVAE(config).to(dev).train()
     if world > 1:
-        vdist.configure(model, B * world)
+        vdist.configure(model, global_batch)
     # BENCH_GRAD_BUCKETS=n: n pieces, each sent as soon as backward has filled it (default: one message after backward;
     # 6.4 MB is latency-bound on xGMI either way)
     flat = vdist.FlatGradients(model.parameters(), buckets=int(os.environ.get('BENCH_GRAD_BUCKETS', '1')))
@@ -516,11 +656,12 @@ def whole_model_leg(dev, x_img, B, world, fence, all_reduce_max, steps=10, warmu
     grad_bytes = flat.nbytes
     del model, flat, opt
     torch.cuda.empty_cache()
-    return {'ms_per_step': round(dt / steps * 1e3, 4), 'samples_per_s': B * world * steps / dt, 'steps': steps,
+    return {'ms_per_step': round(dt / steps * 1e3, 4), 'samples_per_s': global_batch * steps / dt, 'steps': steps,
             'allreduce_bytes_per_step': {'gradients': grad_bytes, 'loss_scalars': 6 * 4},
             'loss_mean': val,
             'what': 'example SimpleVAE (nn.Linear 784-512-%d / %d-512-784, Adam) fwd + loss + bwd + flat gradient '
-                    'all-reduce + optimizer step, B=%d per GPU, %d GPU(s)' % (2 * L, L, B, world)}
+                    'all-reduce + optimizer step, global batch %d, B=%d on this GPU, %d GPU(s)'
+                    % (2 * L, L, global_batch, B, world)}
 
 
 def stock_torch_step_rate(logits, noise, x, recon, gz, steps=10):

@@ -35,6 +35,7 @@ def T(*shape, dtype=torch.float32, kind='randn'):
 
 
 LOOP = '--loop' in sys.argv
+QUIET = False      # bench.py imports the config functions and wants their rows, not their lines
 _flush = None
 
 
@@ -66,7 +67,8 @@ def timeit(name, cfg, fn, nbytes, iters=20):
     gbs = nbytes / ms / 1e6
     rows.append({'kernel': name, 'config': cfg, 'ms': round(ms, 5), 'algorithmic_MB': round(nbytes / 1e6, 1),
                  'GBs': round(gbs), 'frac_of_8TBs': round(gbs / 8000, 3)})
-    print('%-26s %-44s %9.4f ms %8.1f MB %6.0f GB/s  %5.1f%%' % (name, cfg, ms, nbytes / 1e6, gbs, gbs / 80), flush=True)
+    if not QUIET:
+        print('%-26s %-44s %9.4f ms %8.1f MB %6.0f GB/s  %5.1f%%' % (name, cfg, ms, nbytes / 1e6, gbs, gbs / 80), flush=True)
 
 
 def gauss(B, L, dtype=torch.float32, philox=False):
@@ -187,11 +189,14 @@ def concat_module(B, L, K):
     # host-bound eager: ~135 us of Python and autograd around ~130 us of kernels)
     m = ConcatReparameterizer(['isotropic_gaussian', 'discrete'], dict(cfgd)).train()
 
+    gkl = torch.ones(B, device=dev)
+
     def fn2():
         z, params = m(logits)
-        ((z * w).sum() + m.kl(params).sum()).backward()
+        torch.autograd.backward([z, m.kl(params)], [w, gkl])      # the decoder's d z and d(sum kl): no torch kernels
         logits.grad = None
-    nb2 = nbytes - B * 4 * (L + K + L)       # no noise tensors read
+    # the row kernels' bytes: fwd logits 4W + sample 4(L+K) + kl; bwd Gaussian logits 8L + gz 4(L+K) + y 4K + gkl + d(logits) 4W
+    nb2 = B * ((4 * W + 4 * (L + K) + 4) + (8 * L + 4 * (L + K) + 4 * K + 4 + 4 * W))
     cfg2 = 'B=%d L=%d K=%d f32 module fwd+kl+bwd, in-kernel noise' % (B, L, K)
     timeit('concat step (eager)', cfg2, fn2, nb2)
     # a fresh leaf for the captured step: autograd ties a leaf's AccumulateGrad node to the stream of its first
@@ -201,7 +206,7 @@ def concat_module(B, L, K):
 
     def fn3():
         z, params = m(lg)
-        ((z * w).sum() + m.kl(params).sum()).backward()
+        torch.autograd.backward([z, m.kl(params)], [w, gkl])
         lg.grad = None
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
@@ -311,32 +316,38 @@ def nll_steps(Tn, B, D):
 def vrnn_sequence(Tn, B, L, D=784):
     """BASELINE config 5 end to end on the hot path: Tn fused posterior/prior steps (vae_amd.vrnn.reparameterize), the
     loss over all steps in one launch pair, and the whole backward -- eager and replayed from one HIP graph.  The
-    recurrence (LSTM, feature nets, decoder) is the host project's and is not here: its outputs are given tensors."""
+    recurrence (LSTM, feature nets, decoder) is the host project's and is not here: its outputs are given tensors,
+    and the decoder's d loss / d z arrives as a given gradient."""
     from vae_amd import vrnn as V
     from vae_amd.reparameterizers import IsotropicGaussian
     cfg = {'reparam_type': 'isotropic_gaussian', 'continuous_size': 2 * L, 'nll_type': 'bernoulli', 'kl_beta': 1.0,
-           'use_prior_kl': True, 'cuda': True, 'half': False}
+           'use_prior_kl': True, 'cuda': True, 'half': False, 'continuous_mut_info': 0, 'discrete_mut_info': 0}
     rep = IsotropicGaussian(cfg).train()
-    enc = [T(B, 2 * L).requires_grad_(True) for _ in range(Tn)]
-    pri = [T(B, 2 * L).requires_grad_(True) for _ in range(Tn)]
     xs = [(T(B, 1, 28, 28, kind='rand') < 0.3).float() for _ in range(Tn)]
-    recons = [T(B, 1, 28, 28).requires_grad_(True) for _ in range(Tn)]
-    w = T(B, L)
+    gz = T(B, L) * (1.0 / (Tn * B))
 
-    def fn():
-        params, zsum = [], 0.0
-        for t in range(Tn):
-            z, p = V.reparameterize(rep, {'encoder_logits': enc[t], 'prior_logits': pri[t], 'x_features': None}, cfg)
-            params.append(p)
-            zsum = zsum + (z['posterior'] * w).sum()
-        out = V.loss_function(rep, cfg, recons, xs, params)
-        torch.autograd.backward([out['loss_mean'] + zsum * (1.0 / (Tn * B))], inputs=enc + pri + recons)
-        for t in enc + pri + recons:
-            t.grad = None
+    def leaves():
+        return ([T(B, 2 * L).requires_grad_(True) for _ in range(Tn)], [T(B, 2 * L).requires_grad_(True) for _ in range(Tn)],
+                [T(B, 1, 28, 28).requires_grad_(True) for _ in range(Tn)])
+
+    def make(enc, pri, recons):
+        def fn():
+            params, zs = [], []
+            for t in range(Tn):
+                z, p = V.reparameterize(rep, {'encoder_logits': enc[t], 'prior_logits': pri[t], 'x_features': None}, cfg)
+                params.append(p)
+                zs.append(z['posterior'])
+            out = V.loss_function(rep, cfg, recons, xs, params)
+            torch.autograd.backward([out['loss_mean']] + zs, [None] + [gz] * Tn, inputs=enc + pri + recons)
+            for t in enc + pri + recons:
+                t.grad = None
+        return fn
     # pair fwd 40L+4 and bwd 48L+8 per step and sample; loss fwd 8D+16, bwd 12D
     nbytes = Tn * B * ((40 * L + 4) + (48 * L + 8) + (8 * D + 16) + 12 * D)
     cfgs = 'T=%d B=%d L=%d %dpx bernoulli f32: %d pair steps + loss over all steps + backward' % (Tn, B, L, D, Tn)
-    timeit('vrnn sequence (eager)', cfgs, fn, nbytes)
+    timeit('vrnn sequence (eager)', cfgs, make(*leaves()), nbytes)
+    # fresh leaves whose first backward runs on the capture's side stream (see concat_module)
+    fn = make(*leaves())
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
@@ -349,6 +360,46 @@ def vrnn_sequence(Tn, B, L, D=784):
     timeit('vrnn sequence (HIP graph)', cfgs, graph.replay, nbytes)
 
 
+def c4_module(B, L=128, F=256, C=3, H=64, W=64):
+    """BASELINE config 4 through the drop-in classes: SequentialReparameterizer(['isotropic_gaussian', 'flow']) built
+    from the reference's config keys (Gaussian L -> dense -> 5 x (MADE, BatchNormFlow, Reverse) of width F; the masked
+    linears are stock GEMMs) and loss_function with the discretized-logistic NLL over 3x64x64 images, forward and
+    backward, in-kernel noise.  Two lines: the latent chain alone (its kernels' bytes next to the GEMMs' time) and the
+    loss alone (the step's byte mover: one pass, 20D + 12 bytes per sample)."""
+    from vae_amd.reparameterizers import SequentialReparameterizer
+    from vae_amd import elbo as E
+    D = C * H * W
+    cfg = {'continuous_size': 2 * L, 'discrete_size': 5, 'half': False, 'cuda': True, 'epochs': 10,
+           'continuous_mut_info': 0, 'discrete_mut_info': 0, 'kl_beta': 1.0, 'use_prior_kl': False, 'flow_type': 'maf',
+           'latent_size': F, 'memory_read_steps': 1, 'reparam_type': 'isotropic_gaussian', 'nll_type': 'disc_logistic'}
+    torch.manual_seed(0)
+    m = SequentialReparameterizer(['isotropic_gaussian', 'flow'], cfg).to(dev).train()
+    logits = T(B, 2 * L).requires_grad_(True)
+    x = (torch.floor(T(B, C, H, W, kind='rand') * 256) / 255.0).clamp(0, 1)
+    recon = T(B, 2 * C, H, W).requires_grad_(True)
+    Fw = m.output_size
+    gzf, gkl = T(B, Fw) * (1.0 / B), torch.full((B,), 1.0 / B, device=dev)
+
+    def chain():
+        z, params = m(logits)
+        torch.autograd.backward([z, m.kl(params)], [gzf, gkl])
+        logits.grad = None
+        for p in m.parameters():
+            p.grad = None
+    # our kernels on the chain: gauss fwd 12L+4 / bwd 20L+4; per MAF block made tail 16F+4 / 24F+4 and BatchNormFlow
+    # 12F+8 / 20F+4; flow KL 4F+8 / 8F
+    chain_bytes = B * ((12 * L + 4) + (20 * L + 4) + 5 * ((16 * Fw + 4) + (24 * Fw + 4) + (12 * Fw + 8) + (20 * Fw + 4))
+                       + (4 * Fw + 8) + 8 * Fw)
+    timeit('c4 latent chain (module)', 'B=%d Gaussian L=%d -> dense -> 5 x (MADE, BatchNormFlow, Reverse) F=%d, fwd+kl+bwd; '
+           'bytes = the tails and KLs only, time includes the stock masked GEMMs' % (B, L, Fw), chain, chain_bytes)
+    kld = T(B, kind='rand')
+
+    def loss():
+        out = E.loss_function(recon, x, kld, 'disc_logistic', kl_beta=1.0)
+        out['loss_mean'].backward()
+        recon.grad = None
+    timeit('c4 loss (module)', 'B=%d %dx%dx%d disc_logistic f32: loss_function fwd (one pass: values + d recon) + backward'
+           % (B, C, H, W), loss, B * (20 * D + 12 + 8))
 def bernoulli(B, K):
     logits, U, gy = T(B, K), T(B, K, kind='rand'), T(B, K)
     y, zh, gl, kl, gkl = T(B, K, kind='e'), T(B, K, kind='e'), T(B, K, kind='e'), T(B, kind='e'), T(B)
@@ -490,6 +541,7 @@ if __name__ == '__main__':
         flow(65536, 512)
         nll_fused(8192, 12288, 2, 'disc_logistic')
         nll_fused(8192, 12288, 1, 'gaussian')
+        c4_module(8192)
     if not want or 'tails' in want:
         print('== flow-layer tails (one MAF / RealNVP block)')
         flowtail(65536, 512)
@@ -503,6 +555,7 @@ if __name__ == '__main__':
         nll(64 * 1024, 784, 0, 'bernoulli T=64 x B=1024')
         nll_steps(64, 1024, 784)
         vrnn_sequence(64, 1024, 128)
+        vrnn_sequence(64, 4096, 128)
     if not want or 'multi' in want:
         print('== multi-sample forms (loss_function K > 1, MSGVAE, likelihood)')
         multi(65536, 512, 784, 4)

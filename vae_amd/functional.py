@@ -682,7 +682,7 @@ def flow_kl(u, logdet, inv_count=None, reduce_fn=None):
 class _GaussPair(torch.autograd.Function):
     @staticmethod
     def forward(ctx, enc, pri, noise_q, noise_p, eps_tol, training, with_prior_kl, seed, offset, row0, mean_scale,
-                want_logvars=True):
+                want_logvars=True, want_means=True):
         ctx.set_materialize_grads(False)
         dev = check_device(enc, pri, noise_q, noise_p)
         B, L = enc.shape[0], enc.shape[1] // 2
@@ -692,17 +692,22 @@ class _GaussPair(torch.autograd.Function):
         lv_q, lv_p = (new(B, L), new(B, L)) if want_logvars else (None, None)
         clamped, kl_pair = new(B, 2 * L), new(B)
         kl_prior = new(B) if with_prior_kl else None
-        means = _scalars(4, dev, B)
+        # without the four mean diagnostics the launch is a pure row kernel (no grid-wide sum, no ticket chain): at the
+        # per-step batches of a VRNN (a few thousand rows, 5-8 us launches) that chain is a third of the launch
+        means = _scalars(4, dev, B) if want_means else None
         if mean_scale is None:
             mean_scale = 1.0 / max(B * L, 1)
         with _Guard(dev):
             call('vae_gauss_pair_fwd', ptr(enc), enc.stride(0), ptr(pri), pri.stride(0), ptr(noise_q), ptr(noise_p),
                  ptr(z_q), ptr(z_p), ptr(lv_q), ptr(lv_p), ptr(clamped), ptr(kl_pair), ptr(kl_prior), ptr(means),
-                 ptr(workspace(dev)), B, L, eps_tol, mean_scale, int(training), seed & _MASK64, offset & _MASK64,
-                 row0, dtype_code(enc), stream_ptr(dev))
+                 ptr(workspace(dev)) if want_means else None, B, L, eps_tol, mean_scale, int(training), seed & _MASK64,
+                 offset & _MASK64, row0, dtype_code(enc), stream_ptr(dev))
         ctx.save_for_backward(enc, pri, noise_q, noise_p)
         ctx.cfg = (eps_tol, training, seed, offset, row0, mean_scale)
         nd = []
+        if means is None:
+            means = torch.empty((0,), dtype=torch.float32, device=dev)
+            nd.append(means)
         if not training:
             z_q, z_p = enc.new_empty((0,)), enc.new_empty((0,))
             nd += [z_q, z_p]
@@ -724,7 +729,7 @@ class _GaussPair(torch.autograd.Function):
         B, L = enc.shape[0], enc.shape[1] // 2
         if not training:
             gz_q = gz_p = None
-        gmeans = None if gmeans is None else gmeans.contiguous().float()
+        gmeans = None if (gmeans is None or gmeans.numel() == 0) else gmeans.contiguous().float()
         g_enc = torch.empty((B, 2 * L), dtype=enc.dtype, device=dev)
         g_pri = torch.empty_like(g_enc)
         with _Guard(dev):
@@ -732,11 +737,11 @@ class _GaussPair(torch.autograd.Function):
                  ptr(_dense(gz_q)), ptr(_dense(gz_p)), ptr(_dense(glv_q)), ptr(_dense(glv_p)), ptr(_dense(gcl)),
                  ptr(_dense(gkl_pair)), ptr(_dense(gkl_prior)), ptr(gmeans), ptr(g_enc), ptr(g_pri), B, L, eps_tol,
                  mean_scale, int(training), seed & _MASK64, offset & _MASK64, row0, dtype_code(enc), stream_ptr(dev))
-        return g_enc, g_pri, None, None, None, None, None, None, None, None, None, None
+        return g_enc, g_pri, None, None, None, None, None, None, None, None, None, None, None
 
 
 def gauss_pair(enc_logits, prior_logits, noise_post=None, noise_prior=None, eps_tol=1e-6, training=True,
-               with_prior_kl=True, seed=0, offset=0, row0=0, mean_scale=None, want_logvars=True):
+               with_prior_kl=True, seed=0, offset=0, row0=0, mean_scale=None, want_logvars=True, want_means=True):
     """One VRNN step (vrnn.py:419-447 + :723-733) in one launch.  Returns (z_post, z_prior, logvar_post,
     logvar_prior, clamped_prior_logits, kl_pair, kl_prior, means[4]); z_* are None in eval (the caller
     uses the mu views), kl_prior is None unless `with_prior_kl`, the logvars are None (not written) unless
@@ -746,8 +751,10 @@ def gauss_pair(enc_logits, prior_logits, noise_post=None, noise_prior=None, eps_
     nq = None if noise_post is None else noise_post.reshape(B, L).contiguous()
     np_ = None if noise_prior is None else noise_prior.reshape(B, L).contiguous()
     out = _GaussPair.apply(enc, pri, nq, np_, float(eps_tol), bool(training), bool(with_prior_kl), int(seed),
-                           int(offset), int(row0), mean_scale, bool(want_logvars))
+                           int(offset), int(row0), mean_scale, bool(want_logvars), bool(want_means))
     z_q, z_p, lv_q, lv_p, clamped, kl_pair, kl_prior, means = out
+    if not want_means:
+        means = None
     if not want_logvars:
         lv_q = lv_p = None
     return ((z_q if training else None), (z_p if training else None), lv_q, lv_p, clamped, kl_pair,

@@ -66,19 +66,32 @@ def _reparameterize_fused(rep, logits_map, config, noise, force=False):
         seed, offset = rng.next_call()
     z_q, z_p, _, _, clamped, kl_pair, kl_prior, means = F_.gauss_pair(
         enc, pri, noise[0], noise[1], eps_tol=rep.eps_tol, training=training, with_prior_kl=True, seed=seed,
-        offset=offset, row0=rep.row_offset, mean_scale=rep.mean_scale, want_logvars=False)
+        offset=offset, row0=rep.row_offset, mean_scale=rep.mean_scale, want_logvars=False,
+        want_means=bool(config.get('vae_amd_step_means', False)))
     mu_q = torch.narrow(enc, -1, 0, L)
     mu_p = torch.narrow(clamped, -1, 0, L)
     if not training:
         z_q, z_p = mu_q, mu_p
-    means = means.to(enc.dtype)
-    g_q = LazyParams({'z': z_q, 'mu': mu_q, 'mu_mean': means[0], 'logvar_mean': means[1]})
-    g_p = LazyParams({'z': z_p, 'mu': mu_p, 'mu_mean': means[2], 'logvar_mean': means[3]})
+    g_q = LazyParams({'z': z_q, 'mu': mu_q})
+    g_p = LazyParams({'z': z_p, 'mu': mu_p})
     # the logvar entries are the reference's own ops (isotropic_gaussian.py:124-125 on the encoder logits and on the
     # clamped prior logits), run only if somebody reads them: both KLs already came out of the launch
     eps = rep.eps_tol
     g_q.set_lazy('logvar', lambda: torch.narrow(enc, -1, L, L) + eps)
     g_p.set_lazy('logvar', lambda: torch.narrow(clamped, -1, L, L) + eps)
+    if means is not None:
+        means = means.to(enc.dtype)
+        g_q['mu_mean'], g_q['logvar_mean'], g_p['mu_mean'], g_p['logvar_mean'] = means[0], means[1], means[2], means[3]
+    else:
+        # the four diagnostics of isotropic_gaussian.py:213-214, by the reference's own op, if and when they are read:
+        # a per-step launch of a few thousand rows is latency-bound and the grid-wide sum's closing chain was a third
+        # of it (config['vae_amd_step_means'] = True puts them back into the launch)
+        ms = rep.mean_scale
+        red = (lambda t: torch.mean(t)) if ms is None else (lambda t, c=ms: torch.sum(t) * c)
+        g_q.set_lazy('mu_mean', lambda: red(mu_q))
+        g_q.set_lazy('logvar_mean', lambda: red(g_q['logvar']))
+        g_p.set_lazy('mu_mean', lambda: red(mu_p))
+        g_p.set_lazy('logvar_mean', lambda: red(g_p['logvar']))
     g_q._vae_amd_kl_pair = (kl_pair, g_p)        # KL(post || prior), valid against exactly this prior
     g_p._vae_amd_kl = (kl_prior, mu_p)           # KL(prior || N(0,1))
     logits_map['prior_logits'] = clamped
