@@ -178,7 +178,12 @@ __device__ __forceinline__ void store_vec(bool nts, T* __restrict__ p, const flo
       // no difference, every load of a tile is issued before its first store.
       // The s_nop is the wait state the hardware needs between a store of more than 64 bits and a VALU write of its
       // data registers: the compiler pads its own stores, it cannot see this one (without it bernoulli_bwd stored
-      // values of the next chunk: tests/test_gpu_bigindex.py).
+      // values of the next chunk: tests/test_gpu_bigindex.py).  The hazard, by name: "VMEM store of more than 8 bytes
+      // of data followed by a VALU write of the VGPRs that hold the write data" (CDNA3 / CDNA4 ISA guide, section
+      // "Manually Inserted Wait States (NOPs)"; LLVM GCNHazardRecognizer::checkVALUHazards -> createsVALUHazard), 1
+      // wait state on gfx90a, 2 on gfx940 and later: `s_nop 1` is those two.  tests/test_gpu_ntstore.py drives every
+      // kernel family through this branch against the oracle.
+      static_assert(sizeof(P) == 16, "the wait states below are for a 128-bit store");
       asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(reinterpret_cast<P*>(p)), "v"(raw) : "memory");
     } else {
       *reinterpret_cast<P*>(p) = raw;
