@@ -115,6 +115,20 @@ int vae_gauss_reparam_kl_bwd(const void* logits, int64_t row_stride, const void*
                              int64_t L, float eps_tol, float mean_scale, int training, uint64_t seed,
                              uint64_t offset, int64_t row0, int dtype, vae_stream_t stream);
 
+/* The same two for 4-D logits [B, 2C, H, W] (contiguous), which the reference splits on the CHANNEL dimension
+ * (isotropic_gaussian.py:108-114: mu = logits[:, :C], s = logits[:, C:] + eps) while the KL still sums over the last
+ * dimension only (:170): rows are (b, c, h), W elements each.  noise / z / s_out / gz / gs: [B, C, H, W] contiguous;
+ * kl / gkl: [B, C, H]; glogits: [B, 2C, H, W]; means as above with mean_scale = 1 / (B*C*H*W).  The logits are read
+ * where they are: no repacked [mu(W) | s(W)] copy.                                                              */
+int vae_gauss_reparam_kl_fwd_nchw(const void* logits, const void* noise, void* z, void* s_out, void* kl, float* means,
+                                  float* workspace, int64_t B, int64_t C, int64_t H, int64_t W, float eps_tol,
+                                  float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0,
+                                  int dtype, vae_stream_t stream);
+int vae_gauss_reparam_kl_bwd_nchw(const void* logits, const void* noise, const void* gz, const void* gs, const void* gkl,
+                                  const float* gmeans, void* glogits, int64_t B, int64_t C, int64_t H, int64_t W,
+                                  float eps_tol, float mean_scale, int training, uint64_t seed, uint64_t offset,
+                                  int64_t row0, int dtype, vae_stream_t stream);
+
 /* KL(N(mu_q, s_q) || N(mu_p, s_p)) summed over the last dim; mu_p = s_p = NULL
  * means N(0,1).  reparameterizers/isotropic_gaussian.py:172-190 with
  * torch/distributions/kl.py:468-471 (scale is used as given: no exp).

@@ -156,6 +156,19 @@ def make_gaussian(vae, out):
     torch.manual_seed(9)
     z, params = m(logits)
     out['gauss_3d'] = detach_tree({'logits': logits, 'noise': noise, 'z': z, 'params': params, 'kl': m.kl(params)})
+    # 4-D logits [B, 2C, H, W]: split on the CHANNEL dimension (:108-114), kl over W only -> [B, C, H]
+    torch.manual_seed(6)
+    logits = torch.randn(3, 6, 5, 8, requires_grad=True)
+    m = R.IsotropicGaussian(base_config(continuous_size=6))
+    torch.manual_seed(10)
+    noise = torch.zeros(3, 3, 5, 8).normal_()
+    torch.manual_seed(10)
+    z, params = m(logits)
+    kl = m.kl(params)
+    w, wk = torch.randn(3, 3, 5, 8), torch.randn(3, 3, 5)
+    (g,) = torch.autograd.grad((z * w).sum() + (kl * wk).sum(), logits)
+    out['gauss_4d'] = detach_tree({'logits': logits, 'noise': noise, 'z': z, 'params': params, 'kl': kl, 'w': w, 'wk': wk,
+                                   'grad_logits': g})
 
 
 def make_gumbel(vae, out):

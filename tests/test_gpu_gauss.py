@@ -62,6 +62,50 @@ def test_golden_3d(golden):
     close(kl, g['kl'], atol=1e-4)
 
 
+def test_golden_4d(golden):
+    """[B, 2C, H, W] logits split on channels, read where they are (vae_gauss_reparam_kl_fwd/bwd_nchw): the reference's
+    own run."""
+    g = golden('gauss')['gauss_4d']
+    m = mod(3)
+    logits = g['logits'].to(DEV).requires_grad_(True)
+    z, params = m(logits, noise=g['noise'].to(DEV))
+    assert torch.equal(z.detach().cpu(), g['z'])
+    gp = params['gaussian']
+    assert torch.equal(gp['logvar'].detach().cpu(), g['params']['gaussian']['logvar'])
+    assert torch.equal(gp['mu'].detach().cpu(), g['params']['gaussian']['mu'])
+    close(gp['mu_mean'], g['params']['gaussian']['mu_mean'], atol=1e-6)
+    close(gp['logvar_mean'], g['params']['gaussian']['logvar_mean'], atol=1e-6)
+    kl = m.kl(params)
+    assert kl.shape == g['kl'].shape
+    close(kl, g['kl'], atol=1e-5)
+    (gl,) = torch.autograd.grad((z * g['w'].to(DEV)).sum() + (kl * g['wk'].to(DEV)).sum(), logits)
+    close(gl, g['grad_logits'], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('shape', [(5, 4, 3, 7), (64, 16, 8, 8), (33, 2, 1, 128), (9, 6, 4, 36)])
+@pytest.mark.parametrize('train', [True, False])
+def test_4d_vs_oracle(shape, train):
+    """Ragged and vector-aligned W, training and eval (z = the mu view), values and d(logits) of the whole tensor."""
+    torch.manual_seed(sum(shape))
+    B, C2, H, W = shape
+    C = C2 // 2
+    logits, noise = torch.randn(*shape), torch.randn(B, C, H, W)
+    w, wk = torch.randn(B, C, H, W), torch.randn(B, C, H)
+    lc = logits.clone().requires_grad_(True)
+    z0, p0 = O.gauss_forward(lc, noise, training=train)
+    k0 = O.gauss_kl(p0)
+    (g0,) = torch.autograd.grad((z0 * w).sum() + (k0 * wk).sum() + p0['gaussian']['mu_mean'], lc)
+    m = mod(C)
+    m.train(train)
+    ld = logits.to(DEV).requires_grad_(True)
+    z1, p1 = m(ld, noise=noise.to(DEV))
+    k1 = m.kl(p1)
+    (g1,) = torch.autograd.grad((z1 * w.to(DEV)).sum() + (k1 * wk.to(DEV)).sum() + p1['gaussian']['mu_mean'], ld)
+    assert torch.equal(z1.detach().cpu(), z0.detach())
+    close(k1, k0, rtol=1e-5, atol=1e-4)
+    close(g1, g0, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize('B,L', [(1, 1), (3, 5), (7, 32), (64, 512), (1000, 100), (4096, 1024), (513, 2052)])
 @pytest.mark.parametrize('train', [True, False])
 def test_vs_oracle(B, L, train):

@@ -39,6 +39,20 @@ def test_gaussian(golden, name):
         close(gpp, g['grad_klp_prior_logits'])
 
 
+def test_gaussian_4d(golden):
+    """4-D logits: the channel split (isotropic_gaussian.py:108-114), kl over the last dimension only."""
+    g = golden('gauss')['gauss_4d']
+    logits = g['logits'].clone().requires_grad_(True)
+    z, params = O.gauss_forward(logits, g['noise'])
+    assert torch.equal(z, g['z']) and z.shape == (3, 3, 5, 8)
+    assert torch.equal(params['gaussian']['logvar'], g['params']['gaussian']['logvar'])
+    assert torch.equal(params['gaussian']['mu_mean'], g['params']['gaussian']['mu_mean'])
+    kl = O.gauss_kl(params)
+    assert kl.shape == (3, 3, 5) and torch.equal(kl, g['kl'])
+    (gl,) = torch.autograd.grad((z * g['w']).sum() + (kl * g['wk']).sum(), logits)
+    close(gl, g['grad_logits'])
+
+
 def test_gaussian_closed_form(golden):
     """z = e*(0.5*s)+mu (no exp); KL = sum 0.5*(s^2 + mu^2 - 1 - log s^2), finite for s < 0."""
     g = golden('gauss')['gauss_L32_train']

@@ -36,6 +36,10 @@ SIGNATURES = {
                                  _p],
     'vae_gauss_reparam_kl_bwd': [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i64, _i64, _i64, _f, _f, _i, _u64, _u64, _i64,
                                  _i, _p],
+    'vae_gauss_reparam_kl_fwd_nchw': [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _f, _i, _u64, _u64, _i64, _i,
+                                      _p],
+    'vae_gauss_reparam_kl_bwd_nchw': [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _f, _i, _u64, _u64, _i64,
+                                      _i, _p],
     'vae_gauss_kl_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i, _p],
     'vae_gauss_kl_bwd': [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
     'vae_gauss_pair_fwd': [_p, _i64, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _f, _f, _i,

@@ -24,6 +24,19 @@ namespace vae {
 #endif
 constexpr bool kNtGaussFwd = VAE_NT_GAUSS_FWD != 0, kNtGaussBwd = VAE_NT_GAUSS_BWD != 0;
 
+// Where a row's mu and s vectors live.  group == 0: the [B, 2L] layout (mu at row * row_stride, s right behind it at
+// + L).  group > 0: 4-D logits [B, 2C, H, W] split on the CHANNEL dimension (isotropic_gaussian.py:108-114) with the
+// reduction over W only: the rows are (b, c, h), L = W, `group` = C*H rows of stride row_stride = W per sample, samples
+// `group_stride` = 2*C*H*W apart, and a row's s vector s_off = C*H*W elements behind its mu vector.
+struct RowGroups {
+  int64_t group, group_stride, s_off;
+  __device__ __forceinline__ int64_t offset(int64_t row, int64_t row_stride) const {
+    if (!group) return row * row_stride;
+    const int64_t b = row / group;
+    return b * group_stride + (row - b * group) * row_stride;
+  }
+};
+
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
@@ -31,7 +44,8 @@ template <typename T, int V, int U>
 __global__ __launch_bounds__(kBlock) void gauss_fwd_kernel(
     const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ noise, T* __restrict__ z,
     int64_t z_stride, T* __restrict__ s_out, T* __restrict__ kl, float* __restrict__ ws, float mean_scale,
-    float* __restrict__ means, int64_t B, int L, float eps_tol, int training, uint64_t seed, uint64_t offset, int64_t row0, int G, int64_t tiles) {
+    float* __restrict__ means, int64_t B, int L, float eps_tol, int training, uint64_t seed, uint64_t offset, int64_t row0, int G, int64_t tiles,
+    RowGroups rg) {
   offset = resolve_offset(offset);
   const int rpb = kBlock / G;
   const bool nts = nt_stores((int64_t)B * L * (int64_t)sizeof(T));
@@ -44,11 +58,12 @@ __global__ __launch_bounds__(kBlock) void gauss_fwd_kernel(
     const int64_t row = t * rpb + rloc;
     float klr = 0.f;
     if (row < B) {
-      const T* lrow = logits + row * row_stride;
+      const T* lrow = logits + rg.offset(row, row_stride);
+      const int64_t s_off = rg.group ? rg.s_off : L;
       for (int j0 = sub; j0 < nvec; j0 += G * U) {
         float mu[U][V], s[U][V], e[U][V];
         load_chunk<T, V, U, kNtGaussFwd>(lrow, j0, G, nvec, mu);
-        load_chunk<T, V, U, kNtGaussFwd>(lrow + L, j0, G, nvec, s);
+        load_chunk<T, V, U, kNtGaussFwd>(lrow + s_off, j0, G, nvec, s);
         if (training && noise) load_chunk<T, V, U, kNtGaussFwd>(noise + row * L, j0, G, nvec, e);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -93,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void gauss_bwd_kernel(
     const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ noise, const T* __restrict__ gz,
     int64_t gz_stride, const T* __restrict__ gs, const T* __restrict__ gkl, const float* __restrict__ gmeans,
     T* __restrict__ glogits, int64_t gl_stride, int64_t B, int L, float eps_tol, float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0,
-    int G, int64_t tiles) {
+    int G, int64_t tiles, RowGroups rg) {
   offset = resolve_offset(offset);
   const int rpb = kBlock / G;
   const bool nts = nt_stores((int64_t)B * L * (int64_t)sizeof(T));
@@ -107,13 +122,14 @@ __global__ __launch_bounds__(kBlock) void gauss_bwd_kernel(
   for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
     const int64_t row = t * rpb + rloc;
     if (row >= B) continue;
-    const T* lrow = logits + row * row_stride;
-    T* grow = glogits + row * gl_stride;
+    const T* lrow = logits + rg.offset(row, row_stride);
+    T* grow = glogits + rg.offset(row, gl_stride);     // the gradient has the logits' layout
+    const int64_t s_off = rg.group ? rg.s_off : L;
     const float gk = gkl ? to_f32(gkl[row]) : 0.f;
     for (int j0 = sub; j0 < nvec; j0 += G * U) {
       float mu[U][V], s[U][V], e[U][V], g[U][V], g2[U][V];
       load_chunk<T, V, U, kNtGaussBwd>(lrow, j0, G, nvec, mu);
-      load_chunk<T, V, U, kNtGaussBwd>(lrow + L, j0, G, nvec, s);
+      load_chunk<T, V, U, kNtGaussBwd>(lrow + s_off, j0, G, nvec, s);
       if (gz) load_chunk<T, V, U, kNtGaussBwd>(gz + row * gz_stride, j0, G, nvec, g);
       if (gs) load_chunk<T, V, U, kNtGaussBwd>(gs + row * L, j0, G, nvec, g2);
       if (use_e && noise) load_chunk<T, V, U, kNtGaussBwd>(noise + row * L, j0, G, nvec, e);
@@ -132,7 +148,7 @@ __global__ __launch_bounds__(kBlock) void gauss_bwd_kernel(
             ds[i] = (use_e ? 0.5f * e[u][i] * gzi : 0.f) + (gs ? g2[u][i] : 0.f) + gk * (si - fast_rcp(si)) + gm_s;
           }
           store_vec<T, V>(nts, grow + (int64_t)j * V, dmu);
-          store_vec<T, V>(nts, grow + L + (int64_t)j * V, ds);
+          store_vec<T, V>(nts, grow + s_off + (int64_t)j * V, ds);
         }
       }
     }
@@ -257,10 +273,10 @@ static int gauss_fwd_dispatch(const void* logits, int64_t row_stride, const void
                               void* s_out,
                               void* kl, float* means, float* workspace, int64_t B, int64_t L, float eps_tol,
                               float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0,
-                              hipStream_t stream) {
+                              hipStream_t stream, RowGroups rg = RowGroups{0, 0, 0}) {
   constexpr int VN = VecOf<T>::n;
   const bool vec = (L % VN == 0) && (row_stride % VN == 0) && (z_stride % VN == 0) && aligned16(logits) &&
-                   (!z || aligned16(z)) &&
+                   (!z || aligned16(z)) && (rg.group_stride % VN == 0) && (rg.s_off % VN == 0) &&
                    (!noise || aligned16(noise)) && (!s_out || aligned16(s_out));
   const RowGeom g = gauss_geom(B, vec ? L / VN : L, means ? kGridReduce : kGridStream, training && !noise, true);
   if (!means) workspace = nullptr;
@@ -268,12 +284,12 @@ static int gauss_fwd_dispatch(const void* logits, int64_t row_stride, const void
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gauss_fwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
                                          (const T*)logits, row_stride, (const T*)noise, (T*)z, z_stride, (T*)s_out, (T*)kl,
                                          workspace, mean_scale, means, B, (int)L, eps_tol, training, seed, offset,
-                                         row0, g.G, g.tiles));
+                                         row0, g.G, g.tiles, rg));
   } else {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gauss_fwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, stream,
                                          (const T*)logits, row_stride, (const T*)noise, (T*)z, z_stride, (T*)s_out, (T*)kl,
                                          workspace, mean_scale, means, B, (int)L, eps_tol, training, seed, offset,
-                                         row0, g.G, g.tiles));
+                                         row0, g.G, g.tiles, rg));
   }
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
@@ -283,22 +299,22 @@ static int gauss_bwd_dispatch(const void* logits, int64_t row_stride, const void
                               int64_t gz_stride, const void* gs, const void* gkl, const float* gmeans, void* glogits,
                               int64_t gl_stride, int64_t B,
                               int64_t L, float eps_tol, float mean_scale, int training, uint64_t seed,
-                              uint64_t offset, int64_t row0, hipStream_t stream) {
+                              uint64_t offset, int64_t row0, hipStream_t stream, RowGroups rg = RowGroups{0, 0, 0}) {
   constexpr int VN = VecOf<T>::n;
   const bool vec = (L % VN == 0) && (row_stride % VN == 0) && (gz_stride % VN == 0) && (gl_stride % VN == 0) &&
-                   aligned16(logits) && aligned16(glogits) &&
+                   aligned16(logits) && aligned16(glogits) && (rg.group_stride % VN == 0) && (rg.s_off % VN == 0) &&
                    (!noise || aligned16(noise)) && (!gz || aligned16(gz)) && (!gs || aligned16(gs));
   const RowGeom g = gauss_geom(B, vec ? L / VN : L, kGridStream, training && !noise, false);
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gauss_bwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
                                          (const T*)logits, row_stride, (const T*)noise, (const T*)gz, gz_stride,
                                          (const T*)gs, (const T*)gkl, gmeans, (T*)glogits, gl_stride, B, (int)L, eps_tol, mean_scale, training,
-                                         seed, offset, row0, g.G, g.tiles));
+                                         seed, offset, row0, g.G, g.tiles, rg));
   } else {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gauss_bwd_kernel<T, 1, U>), dim3(g.grid), dim3(kBlock), 0, stream,
                                          (const T*)logits, row_stride, (const T*)noise, (const T*)gz, gz_stride,
                                          (const T*)gs, (const T*)gkl, gmeans, (T*)glogits, gl_stride, B, (int)L, eps_tol, mean_scale, training,
-                                         seed, offset, row0, g.G, g.tiles));
+                                         seed, offset, row0, g.G, g.tiles, rg));
   }
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
@@ -395,6 +411,50 @@ int vae_gauss_reparam_kl_bwd(const void* logits, int64_t row_stride, const void*
     return gauss_bwd_dispatch<f16_t>(logits, row_stride, noise, gz, gz_stride, gs, gkl, gmeans, glogits, glogits_stride,
                                       B, L, eps_tol,
                                       mean_scale, training, seed, offset, row0, st);
+  return VAE_ERR_ARG;
+}
+
+int vae_gauss_reparam_kl_fwd_nchw(const void* logits, const void* noise, void* z, void* s_out, void* kl, float* means,
+                                  float* workspace, int64_t B, int64_t C, int64_t H, int64_t W, float eps_tol,
+                                  float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0,
+                                  int dtype, vae_stream_t stream) {
+  if (B < 0 || C <= 0 || H <= 0 || W <= 0 || W > VAE_MAX_ROW) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  if (!logits || (!z && training) || !kl || !workspace) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const RowGroups rg{C * H, 2 * C * H * W, C * H * W};
+  const int64_t rows = B * C * H;
+  if (dtype == VAE_F32)
+    return gauss_fwd_dispatch<float>(logits, W, noise, z, W, s_out, kl, means, workspace, rows, W, eps_tol, mean_scale,
+                                     training, seed, offset, row0, st, rg);
+  if (dtype == VAE_BF16)
+    return gauss_fwd_dispatch<bf16_t>(logits, W, noise, z, W, s_out, kl, means, workspace, rows, W, eps_tol, mean_scale,
+                                      training, seed, offset, row0, st, rg);
+  if (dtype == VAE_F16)
+    return gauss_fwd_dispatch<f16_t>(logits, W, noise, z, W, s_out, kl, means, workspace, rows, W, eps_tol, mean_scale,
+                                     training, seed, offset, row0, st, rg);
+  return VAE_ERR_ARG;
+}
+
+int vae_gauss_reparam_kl_bwd_nchw(const void* logits, const void* noise, const void* gz, const void* gs, const void* gkl,
+                                  const float* gmeans, void* glogits, int64_t B, int64_t C, int64_t H, int64_t W,
+                                  float eps_tol, float mean_scale, int training, uint64_t seed, uint64_t offset,
+                                  int64_t row0, int dtype, vae_stream_t stream) {
+  if (B < 0 || C <= 0 || H <= 0 || W <= 0 || W > VAE_MAX_ROW) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  if (!logits || !glogits) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const RowGroups rg{C * H, 2 * C * H * W, C * H * W};
+  const int64_t rows = B * C * H;
+  if (dtype == VAE_F32)
+    return gauss_bwd_dispatch<float>(logits, W, noise, gz, W, gs, gkl, gmeans, glogits, W, rows, W, eps_tol, mean_scale,
+                                     training, seed, offset, row0, st, rg);
+  if (dtype == VAE_BF16)
+    return gauss_bwd_dispatch<bf16_t>(logits, W, noise, gz, W, gs, gkl, gmeans, glogits, W, rows, W, eps_tol, mean_scale,
+                                      training, seed, offset, row0, st, rg);
+  if (dtype == VAE_F16)
+    return gauss_bwd_dispatch<f16_t>(logits, W, noise, gz, W, gs, gkl, gmeans, glogits, W, rows, W, eps_tol, mean_scale,
+                                     training, seed, offset, row0, st, rg);
   return VAE_ERR_ARG;
 }
 

@@ -117,6 +117,61 @@ def gauss_reparam_kl(logits, noise=None, eps_tol=1e-6, training=True, seed=0, of
     return (z if training else None), (logvar if want_logvar else None), kl, means
 
 
+class _GaussReparamKLNchw(torch.autograd.Function):
+    """4-D logits [B, 2C, H, W] split on the channel dimension, read where they are (no [mu(W) | s(W)] repack)."""
+
+    @staticmethod
+    def forward(ctx, logits, noise, eps_tol, training, seed, offset, row0, mean_scale):
+        ctx.set_materialize_grads(False)
+        dev = check_device(logits, noise)
+        B, C2, H, W = logits.shape
+        C = C2 // 2
+        z = torch.empty((B, C, H, W), dtype=logits.dtype, device=dev) if training else None
+        kl = torch.empty((B, C, H), dtype=logits.dtype, device=dev)
+        means = _scalars(2, dev, B)
+        if mean_scale is None:
+            mean_scale = 1.0 / max(B * C * H * W, 1)
+        with _Guard(dev):
+            call('vae_gauss_reparam_kl_fwd_nchw', ptr(logits), ptr(noise), ptr(z), None, ptr(kl), ptr(means),
+                 ptr(workspace(dev)), B, C, H, W, eps_tol, mean_scale, int(training), seed & _MASK64, offset & _MASK64,
+                 row0, dtype_code(logits), stream_ptr(dev))
+        ctx.save_for_backward(logits, noise)
+        ctx.cfg = (eps_tol, training, seed, offset, row0, mean_scale)
+        if z is None:
+            z = logits.new_empty((0,))
+            ctx.mark_non_differentiable(z)
+        return z, kl, means
+
+    @staticmethod
+    def backward(ctx, gz, gkl, gmeans):
+        logits, noise = ctx.saved_tensors
+        eps_tol, training, seed, offset, row0, mean_scale = ctx.cfg
+        dev = logits.device
+        B, C2, H, W = logits.shape
+        if not training:
+            gz = None
+        gz, gkl = _dense(gz), _dense(gkl)
+        gmeans = None if gmeans is None else gmeans.contiguous().float()
+        glogits = torch.empty_like(logits)
+        with _Guard(dev):
+            call('vae_gauss_reparam_kl_bwd_nchw', ptr(logits), ptr(noise), ptr(gz), None, ptr(gkl), ptr(gmeans),
+                 ptr(glogits), B, C2 // 2, H, W, eps_tol, mean_scale, int(training), seed & _MASK64, offset & _MASK64,
+                 row0, dtype_code(logits), stream_ptr(dev))
+        return glogits, None, None, None, None, None, None, None
+
+
+def gauss_reparam_kl_nchw(logits, noise=None, eps_tol=1e-6, training=True, seed=0, offset=0, row0=0, mean_scale=None):
+    """logits [B, 2C, H, W] -> (z [B, C, H, W] or None in eval, kl [B, C, H], means float32[2]): the reference's
+    channel split for 4-D logits (isotropic_gaussian.py:108-114) with the KL over the last dimension only (:170)."""
+    logits = logits.contiguous()
+    B, C2, H, W = logits.shape
+    if noise is not None:
+        noise = noise.reshape(B, C2 // 2, H, W).to(logits.dtype).contiguous()
+    z, kl, means = _GaussReparamKLNchw.apply(logits, noise, float(eps_tol), bool(training), int(seed), int(offset),
+                                             int(row0), mean_scale)
+    return (z if training else None), kl, means
+
+
 class _GaussKL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mu_q, s_q, mu_p, s_p):

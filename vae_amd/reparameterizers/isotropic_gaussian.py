@@ -77,22 +77,21 @@ class IsotropicGaussian(nn.Module):
         training = bool(self.training or force)
         mu = torch.narrow(logits, dim2slice, 0, L)  # a view of logits, as in the reference
 
-        if logits.dim() == 4:
-            # [B, C, H, W] sliced on channels, KL summed over W only: repack rows as [mu(W) | s(W)]
-            W = logits.shape[-1]
-            s_raw = torch.narrow(logits, dim2slice, L, L)
-            rows = torch.cat([mu.reshape(-1, W), s_raw.reshape(-1, W)], -1)
-            out_shape, kl_shape = mu.shape, mu.shape[:-1]
-        else:
-            rows = logits
-            out_shape, kl_shape = mu.shape, mu.shape[:-1]
-
+        out_shape, kl_shape = mu.shape, mu.shape[:-1]
         seed, offset = (0, 0)
         if training and noise is None:
             seed, offset = rng.next_call()
-        z, _, kl, means = F_.gauss_reparam_kl(rows, noise=noise, eps_tol=self.eps_tol, training=training, seed=seed,
-                                              offset=offset, row0=self.row_offset, mean_scale=self.mean_scale,
-                                              want_logvar=False)
+        if logits.dim() == 4:
+            # [B, 2C, H, W] split on channels, KL summed over W only: the kernel walks the (b, c, h) rows of the
+            # tensor where it is (vae_gauss_reparam_kl_fwd_nchw), no repacked copy
+            z, kl, means = F_.gauss_reparam_kl_nchw(logits, noise=noise, eps_tol=self.eps_tol, training=training,
+                                                    seed=seed, offset=offset, row0=self.row_offset,
+                                                    mean_scale=None if self.mean_scale is None else
+                                                    self.mean_scale / (logits.shape[2] * logits.shape[3]))
+        else:
+            z, _, kl, means = F_.gauss_reparam_kl(logits, noise=noise, eps_tol=self.eps_tol, training=training,
+                                                  seed=seed, offset=offset, row0=self.row_offset,
+                                                  mean_scale=self.mean_scale, want_logvar=False)
         z = z.reshape(out_shape) if training else mu
         g = LazyParams({'z': z, 'mu': mu})
         # the reference's own op (isotropic_gaussian.py:124-125), run only if somebody reads the entry
