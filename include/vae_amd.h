@@ -408,6 +408,15 @@ int vae_nll_steps_elbo_bwd(const void* const* xs, const void* const* recons, voi
 int vae_made_tail_fwd(const void* x, int64_t stride_x, const void* m, int64_t stride_m, const void* a, int64_t stride_a,
                       void* u, const void* logdet_in, void* logdet_out, int64_t B, int64_t F, int pre_exp_tanh,
                       int dtype, vae_stream_t stream);
+/* The same launch, which also leaves the column moments of u -- what the BatchNormFlow that follows a MADE in every
+ * MAF block (flows/__init__.py:582-593) needs first -- as block partials in that layer's `bn_stats` buffer
+ * (vae_bnflow_stats_floats(F) floats): vae_bnflow_fwd with training == 2 then skips its own pass over u for the
+ * statistics (a MAF block forward moves 24F + 12 bytes per row instead of 28F + 12).  Rows of up to 4 * 256 16-byte
+ * vectors, 16-byte aligned (vae_made_tail_moments_supported; VAE_ERR_ARG otherwise: use the two plain calls).   */
+int vae_made_tail_moments_supported(int64_t F, int dtype);
+int vae_made_tail_fwd_moments(const void* x, int64_t stride_x, const void* m, int64_t stride_m, const void* a,
+                              int64_t stride_a, void* u, const void* logdet_in, void* logdet_out, float* bn_stats,
+                              int64_t B, int64_t F, int pre_exp_tanh, int dtype, vae_stream_t stream);
 /* gu [B, F] / glogdet [B] (each may be NULL) -> gx [B, F] (may be NULL), gm, ga (strided, the raw
  * pre-tanh a when pre_exp_tanh); uses the saved output u.                                        */
 int vae_made_tail_bwd(const void* u, const void* a, int64_t stride_a, const void* gu, const void* glogdet, void* gx,
@@ -426,7 +435,8 @@ int vae_coupling_tail_bwd(const void* x, const void* s_raw, const float* mask, c
  * :403-406, when `reverse`: y is stored in reversed column order].
  *   training: batch mean and var = mean((x - mean)^2) + eps over the B rows of THIS call, from one
  *   read of x (shifted sums, block partials added in block order in double); else mean_in / var_in
- *   (the running statistics).  y = exp(log_gamma) * (x - mean) / sqrt(var) + beta;
+ *   (the running statistics).  training == 2: as training, but the block partials of x's column moments are
+ *   already in `stats`, left there by vae_made_tail_fwd_moments whose output u is this call's x (same B, F).  y = exp(log_gamma) * (x - mean) / sqrt(var) + beta;
  *   logdet = sum_f (log_gamma - 0.5 log var).  log_gamma, beta, mean_in, var_in: F floats.
  *   stats: caller-owned fp32 scratch of vae_bnflow_stats_floats(F) floats, kept for the backward:
  *   [0,F) mean | [F,2F) var | [2F,3F) 1/sqrt(var) | [3F,4F) scale | [4F,5F) beta | [5F,6F) logdet terms |

@@ -442,16 +442,19 @@ def nll(B, D, code, name, dtype=torch.float32):
     timeit('nll_elbo_bwd', cfg, lambda: call('vae_nll_elbo_bwd', ptr(x), ptr(recon), code, None, None, None, ptr(gm), 1.0, 1.0 / B, ptr(gr), ptr(gk), None, None, B, D, dc, st), B * (D + 2 * R) * es)
 
 
-def nll_fused(B, D, code, name):
+def nll_fused(B, D, code, name, dtype=torch.float32):
     R = D if code == 0 else 2 * D
+    es = 2 if dtype == torch.bfloat16 else 4
+    dc = 1 if dtype == torch.bfloat16 else 0
     x = (T(B, D, kind='rand') * 255).floor().div(255) if code else (T(B, D, kind='rand') < 0.13).float()
-    recon, kld = T(B, R), T(B, kind='rand')
-    n, lo, el, gr = T(B, kind='e'), T(B, kind='e'), T(B, kind='e'), T(B, R, kind='e')
+    x = x.to(dtype)
+    recon, kld = T(B, R, dtype=dtype), T(B, kind='rand', dtype=dtype)
+    n, lo, el, gr = T(B, kind='e', dtype=dtype), T(B, kind='e', dtype=dtype), T(B, kind='e', dtype=dtype), T(B, R, kind='e', dtype=dtype)
     means, gm = torch.zeros(6, device=dev), torch.zeros(6, device=dev)
     gm[0] = 1
-    cfg = 'B=%d D=%d %s f32 (fwd + gradient, one pass)' % (B, D, name)
-    timeit('nll_elbo_fused', cfg, lambda: call('vae_nll_elbo_fused', ptr(x), ptr(recon), code, ptr(kld), None, None, 1.0, 1.0 / B, 1.0, ptr(n), ptr(lo), ptr(el), ptr(means), ptr(ws), ptr(gr), B, D, 0, st), B * ((D + 2 * R) * 4 + 12))
-    timeit('nll_fused_grad_finish', cfg, lambda: call('vae_nll_fused_grad_finish', ptr(gr), ptr(gm), B * R, 0, st), 12)
+    cfg = 'B=%d D=%d %s %s (fwd + gradient, one pass)' % (B, D, name, 'bf16' if dc else 'f32')
+    timeit('nll_elbo_fused', cfg, lambda: call('vae_nll_elbo_fused', ptr(x), ptr(recon), code, ptr(kld), None, None, 1.0, 1.0 / B, 1.0, ptr(n), ptr(lo), ptr(el), ptr(means), ptr(ws), ptr(gr), B, D, dc, st), B * ((D + 2 * R) * es + 3 * es))
+    timeit('nll_fused_grad_finish', cfg, lambda: call('vae_nll_fused_grad_finish', ptr(gr), ptr(gm), B * R, dc, st), 12)
 
 
 def flowtail(B, F):
@@ -466,6 +469,16 @@ def flowtail(B, F):
     stats = torch.empty(_lib.load().vae_bnflow_stats_floats(F), device=dev)
     y, ld2 = T(B, F, kind='e'), T(B, kind='e')
     timeit('bnflow_fwd (stats+apply+reverse)', cfg, lambda: call('vae_bnflow_fwd', ptr(u), ptr(lg), ptr(beta), None, None, ptr(stats), ptr(y), ptr(ld), ptr(ld2), B, F, 1e-5, 1, 1, 0, st), B * (12 * F + 8))
+    if _lib.load().vae_made_tail_moments_supported(F, 0):
+        mom = lambda: call('vae_made_tail_fwd_moments', ptr(x), F, ptr(ma), 2 * F, off(ma, F), 2 * F, ptr(u), None, ptr(ld), ptr(stats), B, F, 0, 0, st)
+        bn2 = lambda: call('vae_bnflow_fwd', ptr(u), ptr(lg), ptr(beta), None, None, ptr(stats), ptr(y), ptr(ld), ptr(ld2), B, F, 1e-5, 2, 1, 0, st)
+        timeit('made_tail_fwd_moments (u + column moments)', cfg, mom, B * (16 * F + 4))
+        timeit('bnflow_fwd (moments given: apply+reverse)', cfg, bn2, B * (8 * F + 8))
+        timeit('MAF block fwd tails, folded (2 launches)', cfg, lambda: (mom(), bn2()), B * (24 * F + 12))
+        timeit('MAF block fwd tails, plain (2 launches)', cfg, lambda: (
+            call('vae_made_tail_fwd', ptr(x), F, ptr(ma), 2 * F, off(ma, F), 2 * F, ptr(u), None, ptr(ld), B, F, 0, 0, st),
+            call('vae_bnflow_fwd', ptr(u), ptr(lg), ptr(beta), None, None, ptr(stats), ptr(y), ptr(ld), ptr(ld2), B, F, 1e-5, 1, 1, 0, st)),
+            B * (28 * F + 12))
     timeit('bnflow_bwd (stats+apply)', cfg, lambda: call('vae_bnflow_bwd', ptr(u), ptr(gu), ptr(gld), ptr(stats), ptr(gx), B, F, 1, 1, 0, st), B * (20 * F + 4))
     s_raw, t_raw, mask = T(B, F) * 0.3, T(B, F), (torch.arange(F, device=dev) % 2).float()
     gs, gt = T(B, F, kind='e'), T(B, F, kind='e')
@@ -522,6 +535,7 @@ if __name__ == '__main__':
             nll(B, 784, 0, 'bernoulli')
         nll(65536, 784, 0, 'bernoulli', dtype=torch.bfloat16)
         nll_fused(65536, 784, 0, 'bernoulli')
+        nll_fused(65536, 784, 0, 'bernoulli', dtype=torch.bfloat16)
     if not want or 'c1' in want:
         print('== C1-sized steps: eager launches vs one HIP graph')
         graph_step(4096, 32)

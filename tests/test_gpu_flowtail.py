@@ -321,3 +321,109 @@ def test_bn_split_phases_equal_the_single_call(B, F, reverse):
     assert calls == [(2 * F + 1,), (2 * F + 1,)]
     for a, b in zip(*res):
         torch.testing.assert_close(b, a, rtol=2e-5, atol=2e-5 * max(1.0, float(a.abs().max())))
+
+
+# ------------------------------------------------------------------ MADE tail that also leaves the BatchNormFlow moments
+@pytest.mark.parametrize('B,Fd', [(1, 4), (2, 8), (37, 64), (300, 128), (1025, 512), (4096, 512), (777, 1024),
+                                  (513, 2048), (260, 4096), (5000, 36)])
+@pytest.mark.parametrize('split', [False, True])
+@pytest.mark.parametrize('reverse', [False, True])
+def test_made_tail_moments_then_bnflow_equals_the_two_plain_calls(B, Fd, split, reverse):
+    """vae_made_tail_fwd_moments + vae_bnflow_fwd(training == 2) against the two plain launches: u and y bit for bit
+    (same shift, same partial geometry, same summation order), logdet to an ulp of the row sum, the same gradients; and
+    both against the oracle (O.made_tail, O.bnflow)."""
+    from vae_amd import functional as F_
+    torch.manual_seed(B * 5 + Fd)
+    x, ma, ld0 = torch.randn(B, Fd) * 2 + 3, torch.randn(B, 2 * Fd) * 0.7, torch.randn(B)
+    lg, beta = torch.randn(Fd) * 0.3, torch.randn(Fd)
+    wu, wl = torch.randn(B, Fd).to(DEV), torch.randn(B).to(DEV)
+    res = []
+    for fold in (False, True):
+        xd, mad, ldd, lgd, bd = [t.to(DEV).requires_grad_(True) for t in (x, ma, ld0, lg, beta)]
+        stats = F_.bn_stats_buffer(xd) if fold else None
+        assert not fold or stats is not None
+        if split:
+            md, ad = mad[:, :Fd].contiguous(), mad[:, Fd:].contiguous()
+            u, l = F_.made_tail(xd, md, ad, logdet_in=ldd, pre_exp_tanh=True, bn_stats=stats)
+        else:
+            u, l = F_.made_tail(xd, mad, None, logdet_in=ldd, bn_stats=stats)
+        y, l2, mean, var = F_.bnflow(u, lgd, bd, logdet_in=l, training=True, reverse=reverse, moments=stats)
+        g = torch.autograd.grad((y * wu).sum() + (l2 * wl).sum(), [xd, mad, ldd, lgd, bd])
+        res.append((u, y, mean, var, l, l2) + g)
+    plain, folded = res
+    for k in range(4):
+        assert torch.equal(plain[k], folded[k]), k
+    for a, b in zip(plain[4:], folded[4:]):
+        torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-5 * max(1.0, float(a.abs().max())))
+    # the oracle
+    u0, l0 = O.made_tail(x, ma[:, :Fd], ma[:, Fd:], pre_exp_tanh=split)
+    y0, lb0, mean0, var0 = O.bnflow(u0, lg, beta, None, None, training=True)
+    if reverse:
+        y0 = O.reverse_columns(y0)
+    close(folded[0], u0, rtol=1e-5, atol=1e-5)
+    close(folded[2], mean0, rtol=1e-5, atol=1e-5)
+    close(folded[3], var0, rtol=5e-5, atol=1e-6)
+    if B > 1:
+        close(folded[1], y0, rtol=1e-4, atol=1e-4)
+    close(folded[5], ld0 + l0.squeeze(-1) + lb0, rtol=1e-5, atol=2e-5 * Fd ** 0.5)
+
+
+@pytest.mark.parametrize('half', [torch.bfloat16, torch.float16])
+def test_made_tail_moments_16bit(half):
+    from vae_amd import functional as F_
+    torch.manual_seed(11)
+    B, Fd = 1500, 256
+    x, ma = torch.randn(B, Fd).to(half).to(DEV), (torch.randn(B, 2 * Fd) * 0.5).to(half).to(DEV)
+    lg, beta = (torch.randn(Fd) * 0.3).to(DEV), torch.randn(Fd).to(DEV)
+    u0, l0 = F_.made_tail(x, ma)
+    y0, ll0, m0, v0 = F_.bnflow(u0, lg, beta, logdet_in=l0, training=True, reverse=True)
+    stats = F_.bn_stats_buffer(x)
+    u1, l1 = F_.made_tail(x, ma, bn_stats=stats)
+    y1, ll1, m1, v1 = F_.bnflow(u1, lg, beta, logdet_in=l1, training=True, reverse=True, moments=stats)
+    assert torch.equal(u0, u1) and torch.equal(y0, y1) and torch.equal(m0, m1) and torch.equal(v0, v1)
+    close(ll1, ll0, rtol=1e-2, atol=0.5)
+
+
+def test_made_tail_moments_unsupported_shapes_and_modes():
+    from vae_amd import functional as F_
+    from vae_amd import _lib
+    lib = _lib.load()
+    assert lib.vae_made_tail_moments_supported(512, 0) == 1
+    assert lib.vae_made_tail_moments_supported(510, 0) == 0       # not a whole number of 16-byte vectors
+    assert lib.vae_made_tail_moments_supported(4 * 4 * 256 + 4, 0) == 0   # wider than one column window
+    assert F_.bn_stats_buffer(torch.zeros(4, 510, device=DEV)) is None
+    # eval mode / cross-rank statistics ignore a moments buffer (the running statistics / the split phases are used)
+    x = torch.randn(64, 32, device=DEV)
+    lg, beta = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+    junk = torch.full((lib.vae_bnflow_stats_floats(32),), float('nan'), device=DEV)
+    y, ld, _, _ = F_.bnflow(x, lg, beta, torch.zeros(32, device=DEV), torch.ones(32, device=DEV), training=False,
+                            moments=junk)
+    assert bool(torch.isfinite(y).all())
+
+
+def test_flow_sequential_pairs_made_with_batchnorm(monkeypatch):
+    """FlowSequential routes MADE -> BatchNormFlow through the folded launch in training (one launch fewer per block) and
+    the result equals the unpaired layers'."""
+    from vae_amd import flows, functional as F_
+    torch.manual_seed(3)
+    net = flows.build_maf_flow(64, 128, num_blocks=3).to(DEV).train()
+    x = torch.randn(512, 64, device=DEV)
+    seen = []
+    real = F_.made_tail
+
+    def spy(*a, **k):
+        seen.append(k.get('bn_stats') is not None)
+        return real(*a, **k)
+    monkeypatch.setattr(F_, 'made_tail', spy)
+    u1, ld1 = net(x)
+    assert seen and all(seen)
+    seen.clear()
+    monkeypatch.setattr(F_, 'bn_stats_buffer', lambda x: None)
+    u0, ld0 = net(x)
+    assert seen and not any(seen)
+    torch.testing.assert_close(u1, u0, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(ld1, ld0, rtol=1e-5, atol=1e-4)
+    net.eval()
+    seen.clear()
+    net(x)
+    assert not any(seen)

@@ -82,6 +82,8 @@ SIGNATURES = {
                                _i, _p],
     'vae_nll_steps_elbo_bwd': [_pp, _pp, _pp, _i64, _i, _p, _p, _p, _p, _fp, _f, _f, _p, _p, _p, _i64, _i64, _i, _p],
     'vae_made_tail_fwd': [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _i, _p],
+    'vae_made_tail_moments_supported': [_i64, _i],
+    'vae_made_tail_fwd_moments': [_p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _i, _i, _p],
     'vae_made_tail_bwd': [_p, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _i, _i, _p],
     'vae_coupling_tail_fwd': [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],
     'vae_coupling_tail_bwd': [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i, _p],

@@ -356,6 +356,136 @@ __global__ __launch_bounds__(kBlock) void bn_colstats_kernel(
   if (threadIdx.x == 0 && jbase == 0) mypart[2 * (size_t)F] = ex[0] + ex[1] + ex[2] + ex[3];
 }
 
+// MADE tail AND the column moments of its output, for the BatchNormFlow that follows it in every MAF block
+// (flows/__init__.py:582-593: MADE, BatchNormFlow, Reverse): u is written once and its moments are taken from the
+// registers that hold it, so the BatchNormFlow forward no longer reads u a first time for its statistics (a MAF block
+// forward moves 24F + 12 bytes per row instead of 28F + 12).  Geometry and partial layout are bn_colstats_kernel's
+// (mode 0: shifted sums, the shift being u[0, :], which every lane forms for its own columns from row 0).
+// The values entering the sums are u as STORED (rounded to the tensor dtype): what BatchNormFlow would read back.
+template <typename T, int V, int NJ, int R>
+__global__ __launch_bounds__(kBlock) void made_tail_moments_fwd_kernel(
+    const T* __restrict__ x, int64_t sx, const T* __restrict__ m, int64_t sm, const T* __restrict__ a, int64_t sa,
+    T* __restrict__ u, const T* __restrict__ ld_in, T* __restrict__ ld_out, float* __restrict__ part, int64_t B, int F,
+    int pre_tanh, int G, int64_t tiles) {
+  __shared__ float lds[NJ * V * kBlock];
+  __shared__ float wsum[kBlock / 64];
+  const int rpb = kBlock / G;
+  const bool nts = nt_stores((int64_t)B * F * (int64_t)sizeof(T));
+  const int sub = threadIdx.x % G;
+  const int rloc = threadIdx.x / G;
+  const int nvec = F / V;
+  float a1[NJ][V], a2[NJ][V], c0[NJ][V];
+  int jc[NJ];
+  bool jv[NJ];
+  auto tail = [&](const float (&xv)[V], const float (&mv)[V], const float (&av)[V], float (&o)[V], float& s) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float ai = pre_tanh ? tanh_acc(av[i]) : av[i];
+      o[i] = (xv[i] - mv[i]) * exp_acc(-ai);
+      s -= ai;
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < NJ; ++k) {
+    const int j = sub + k * G;
+    jv[k] = j < nvec;
+    jc[k] = jv[k] ? j : nvec - 1;
+    float xv[V], mv[V], av[V], o[V], dummy = 0.f;
+    load_vec<T, V, false>(x + (int64_t)jc[k] * V, xv);
+    load_vec<T, V, false>(m + (int64_t)jc[k] * V, mv);
+    load_vec<T, V, false>(a + (int64_t)jc[k] * V, av);
+    tail(xv, mv, av, o, dummy);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      c0[k][i] = to_f32(from_f32<T>(o[i]));
+      a1[k][i] = 0.f;
+      a2[k][i] = 0.f;
+    }
+  }
+  for (int64_t t0 = blockIdx.x; t0 < tiles; t0 += (int64_t)gridDim.x * R) {
+    float xv[R][NJ][V], mv[R][NJ][V], av[R][NJ][V];
+    bool rv[R];
+    int64_t rows[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t t = t0 + (int64_t)r * gridDim.x;
+      const int64_t row = t * rpb + rloc;
+      rv[r] = t < tiles && row < B;
+      rows[r] = rv[r] ? row : 0;
+#pragma unroll
+      for (int k = 0; k < NJ; ++k) {
+        load_vec<T, V>(x + rows[r] * sx + (int64_t)jc[k] * V, xv[r][k]);
+        load_vec<T, V>(m + rows[r] * sm + (int64_t)jc[k] * V, mv[r][k]);
+        load_vec<T, V>(a + rows[r] * sa + (int64_t)jc[k] * V, av[r][k]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < NJ; ++k) {
+        float o[V], sk = 0.f;
+        tail(xv[r][k], mv[r][k], av[r][k], o, sk);
+        const bool ok = rv[r] && jv[k];
+        s += ok ? sk : 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const float d = ok ? to_f32(from_f32<T>(o[i])) - c0[k][i] : 0.f;
+          a1[k][i] += d;
+          a2[k][i] += d * d;
+        }
+        if (ok) store_vec<T, V>(nts, u + rows[r] * F + (int64_t)jc[k] * V, o);
+      }
+      // every thread of the block reaches this (uniform trip counts); bn_geom's G may be 128: two rows a block
+      if (G <= 64) {
+        s = group_sum(s, G);
+      } else {
+        s = group_sum(s, 64);
+        lds_barrier();
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+        lds_barrier();
+        s = 0.f;
+        for (int w = 0; w < G / 64; ++w) s += wsum[rloc * (G / 64) + w];
+      }
+      if (rv[r] && sub == 0)
+        ld_out[rows[r]] = from_f32<T>((ld_in ? to_f32(ld_in[rows[r]]) : 0.f) + to_f32(from_f32<T>(s)));
+    }
+  }
+  // fold the rpb rows of the block, one partial per block: bn_colstats_kernel's layout
+  float* mypart = part + (size_t)blockIdx.x * (2 * (size_t)F + 1);
+  if (rpb > 1) {
+    for (int st = 0; st < 2; ++st) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NJ; ++k)
+#pragma unroll
+        for (int i = 0; i < V; ++i) lds[(k * V + i) * kBlock + threadIdx.x] = st ? a2[k][i] : a1[k][i];
+      __syncthreads();
+      for (int q = rloc; q < NJ * V; q += rpb) {
+        const int k = q / V, i = q % V;
+        const int j = sub + k * G;
+        if (j < nvec) {
+          float sum = 0.f;
+          for (int r = 0; r < rpb; ++r) sum += lds[q * kBlock + r * G + sub];
+          mypart[(size_t)st * F + (size_t)j * V + i] = sum;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) {
+      if (jv[k]) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          mypart[(size_t)jc[k] * V + i] = a1[k][i];
+          mypart[(size_t)F + (size_t)jc[k] * V + i] = a2[k][i];
+        }
+      }
+    }
+  }
+  if (threadIdx.x == 0) mypart[2 * (size_t)F] = 0.f;
+}
+
 // Second step: 8 columns x 32 partial-groups per block; block order, double.
 //   mode 0: mean = c + S1/B, var = S2/B - (S1/B)^2 + eps; then the per-column constants of the apply:
 //           rstd, scale = exp(lg) * rstd, beta, ldc = lg - 0.5 log var
@@ -614,6 +744,29 @@ static int made_fwd_dispatch(const void* x, int64_t sx, const void* m, int64_t s
   return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
 }
 
+// the MADE tail that also leaves the column moments of u in the following BatchNormFlow's stats buffer
+template <typename T>
+static int made_moments_dispatch(const void* x, int64_t sx, const void* m, int64_t sm, const void* a, int64_t sa, void* u,
+                                 const void* ld_in, void* ld_out, float* stats, int64_t B, int64_t F, int pre_tanh,
+                                 hipStream_t st) {
+  constexpr int VN = VecOf<T>::n;
+  const bool vec = (F % VN == 0) && (sx % VN == 0) && (sm % VN == 0) && (sa % VN == 0) && aligned16(x) &&
+                   aligned16(m) && aligned16(a) && aligned16(u) && aligned16(stats);
+  if (!vec) return VAE_ERR_ARG;
+  int G, NJ, grid;
+  int64_t tiles;
+  bn_geom(B, F / VN, &G, &NJ, &tiles, &grid);
+  if ((int64_t)G * kBnChunks < F / VN) return VAE_ERR_ARG;   // wider than one column window
+  float* part = stats + 10 * F + 4;
+#define VAE_MADE_MOM(NJ_, R_)                                                                                         \
+  hipLaunchKernelGGL((made_tail_moments_fwd_kernel<T, VN, NJ_, R_>), dim3(grid), dim3(kBlock), 0, st, (const T*)x, sx, \
+                     (const T*)m, sm, (const T*)a, sa, (T*)u, (const T*)ld_in, (T*)ld_out, part, B, (int)F, pre_tanh, G, \
+                     tiles)
+  if (NJ == 1) { VAE_MADE_MOM(1, 2); } else if (NJ == 2) { VAE_MADE_MOM(2, 2); } else { VAE_MADE_MOM(4, 1); }
+#undef VAE_MADE_MOM
+  return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
+}
+
 template <typename T>
 static int made_bwd_dispatch(const void* u, const void* a, int64_t sa, const void* gu, const void* gld, void* gx,
                              void* gm, int64_t sgm, void* ga, int64_t sga, int64_t B, int64_t F, int pre_tanh,
@@ -691,7 +844,10 @@ static int bn_fwd_dispatch(const void* x, const float* lg, const float* beta, co
     int G, NJ, grid;
     int64_t tiles;
     bn_geom(B, vec ? F / VN : F, &G, &NJ, &tiles, &grid);
-    if (vec)
+    if (training == 2) {
+      // the block partials are already in `stats`: vae_made_tail_fwd_moments wrote them (same B, F -> same grid)
+      if (!vec) return VAE_ERR_ARG;
+    } else if (vec)
       bn_colstats_launch<T, VN>(NJ, grid, st, (const T*)x, nullptr, nullptr, nullptr, nullptr, part, B, (int)F, 0, 0, G,
                                 tiles);
     else
@@ -778,6 +934,35 @@ int vae_made_tail_fwd(const void* x, int64_t stride_x, const void* m, int64_t st
     return made_fwd_dispatch<bf16_t>(x, stride_x, m, stride_m, a, stride_a, u, logdet_in, logdet_out, B, F, pre_exp_tanh, st);
   if (dtype == VAE_F16)
     return made_fwd_dispatch<f16_t>(x, stride_x, m, stride_m, a, stride_a, u, logdet_in, logdet_out, B, F, pre_exp_tanh, st);
+  return VAE_ERR_ARG;
+}
+
+int vae_made_tail_moments_supported(int64_t F, int dtype) {
+  if (dtype != VAE_F32 && dtype != VAE_BF16 && dtype != VAE_F16) return 0;
+  const int VN = dtype == VAE_F32 ? 4 : 8;
+  if (F <= 0 || F % VN) return 0;
+  int G, NJ, grid;
+  int64_t tiles;
+  bn_geom(1, F / VN, &G, &NJ, &tiles, &grid);
+  return (int64_t)G * kBnChunks >= F / VN ? 1 : 0;
+}
+
+int vae_made_tail_fwd_moments(const void* x, int64_t stride_x, const void* m, int64_t stride_m, const void* a,
+                              int64_t stride_a, void* u, const void* logdet_in, void* logdet_out, float* bn_stats,
+                              int64_t B, int64_t F, int pre_exp_tanh, int dtype, vae_stream_t stream) {
+  if (B < 0 || F <= 0 || F > VAE_MAX_ROW) return VAE_ERR_ARG;
+  if (B == 0) return VAE_OK;
+  if (!x || !m || !a || !u || !logdet_out || !bn_stats) return VAE_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VAE_F32)
+    return made_moments_dispatch<float>(x, stride_x, m, stride_m, a, stride_a, u, logdet_in, logdet_out, bn_stats, B, F,
+                                        pre_exp_tanh, st);
+  if (dtype == VAE_BF16)
+    return made_moments_dispatch<bf16_t>(x, stride_x, m, stride_m, a, stride_a, u, logdet_in, logdet_out, bn_stats, B, F,
+                                         pre_exp_tanh, st);
+  if (dtype == VAE_F16)
+    return made_moments_dispatch<f16_t>(x, stride_x, m, stride_m, a, stride_a, u, logdet_in, logdet_out, bn_stats, B, F,
+                                        pre_exp_tanh, st);
   return VAE_ERR_ARG;
 }
 

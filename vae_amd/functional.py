@@ -1221,8 +1221,10 @@ def nll_steps_elbo(xs, recons, nll_type, kld=None, add=None, mi=None, kl_beta=1.
 # --------------------------------------------------------------------------------------
 class _MadeTail(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, m, a, logdet_in, pre_tanh):
-        """a None: `m` is the packed [B, 2F] trunk output [m | a] (MADE); else two [B, F] tensors (MADESplit)."""
+    def forward(ctx, x, m, a, logdet_in, pre_tanh, bn_stats=None):
+        """a None: `m` is the packed [B, 2F] trunk output [m | a] (MADE); else two [B, F] tensors (MADESplit).
+        bn_stats: the stats buffer of the BatchNormFlow that consumes u next -- the launch then leaves u's column
+        moments there (vae_made_tail_fwd_moments)."""
         ctx.set_materialize_grads(False)
         dev = check_device(x, m, a, logdet_in)
         B, F = x.shape
@@ -1232,8 +1234,13 @@ class _MadeTail(torch.autograd.Function):
         import ctypes
         a_ptr = ctypes.c_void_p(m.data_ptr() + F * m.element_size()) if packed else ptr(a)
         with _Guard(dev):
-            call('vae_made_tail_fwd', ptr(x), x.stride(0), ptr(m), m.stride(0), a_ptr, m.stride(0) if packed else
-                 a.stride(0), ptr(u), ptr(logdet_in), ptr(ld), B, F, int(pre_tanh), dtype_code(x), stream_ptr(dev))
+            if bn_stats is not None:
+                call('vae_made_tail_fwd_moments', ptr(x), x.stride(0), ptr(m), m.stride(0), a_ptr, m.stride(0) if packed
+                     else a.stride(0), ptr(u), ptr(logdet_in), ptr(ld), ptr(bn_stats), B, F, int(pre_tanh), dtype_code(x),
+                     stream_ptr(dev))
+            else:
+                call('vae_made_tail_fwd', ptr(x), x.stride(0), ptr(m), m.stride(0), a_ptr, m.stride(0) if packed else
+                     a.stride(0), ptr(u), ptr(logdet_in), ptr(ld), B, F, int(pre_tanh), dtype_code(x), stream_ptr(dev))
         ctx.save_for_backward(u, m, a)
         ctx.cfg = (packed, pre_tanh, logdet_in is not None)
         return u, ld
@@ -1260,18 +1267,32 @@ class _MadeTail(torch.autograd.Function):
                  int(pre_tanh), dtype_code(u), stream_ptr(dev))
         gin = gld if has_ld else None
         if packed:
-            return gx, gma, None, gin, None
-        return gx, gm, ga, gin, None
+            return gx, gma, None, gin, None, None
+        return gx, gm, ga, gin, None, None
 
 
-def made_tail(x, m, a=None, logdet_in=None, pre_exp_tanh=False):
+def bn_stats_buffer(x):
+    """The fp32 stats buffer of a BatchNormFlow over x's columns, when the MADE tail in front of it can leave the
+    column moments there (None otherwise)."""
+    F = x.shape[-1]
+    if x.shape[0] == 0 or not _lib.load().vae_made_tail_moments_supported(F, dtype_code(x)):
+        return None
+    return torch.empty((_lib.load().vae_bnflow_stats_floats(F),), dtype=torch.float32, device=x.device)
+
+
+def made_tail(x, m, a=None, logdet_in=None, pre_exp_tanh=False, bn_stats=None):
     """u = (x - m) * exp(-a), logdet_out = logdet_in - sum_f a  (flows/__init__.py:121-125, :176-178).
-    `a` None: `m` is MADE's packed trunk output [B, 2F] = [m | a].  Returns (u [B, F], logdet_out [B])."""
+    `a` None: `m` is MADE's packed trunk output [B, 2F] = [m | a].  Returns (u [B, F], logdet_out [B]).
+    bn_stats (from bn_stats_buffer): also leave u's column moments there for bnflow(..., moments=bn_stats)."""
     x = _rows(x)
     m = _rows(m)
     a = None if a is None else _rows(a)
     ld = None if logdet_in is None else logdet_in.reshape(-1).contiguous()
-    return _MadeTail.apply(x, m, a, ld, bool(pre_exp_tanh))
+    if bn_stats is not None:
+        ok = all(t is None or (t.data_ptr() % 16 == 0 and t.stride(0) % (16 // t.element_size()) == 0) for t in (x, m, a))
+        if not ok:
+            raise ValueError("made_tail(bn_stats=...): inputs must be 16-byte aligned rows")
+    return _MadeTail.apply(x, m, a, ld, bool(pre_exp_tanh), bn_stats)
 
 
 class _CouplingTail(torch.autograd.Function):
@@ -1319,13 +1340,16 @@ class _BNFlow(torch.autograd.Function):
     likewise reduces its 2F+1 column sums between its two kernels."""
 
     @staticmethod
-    def forward(ctx, x, log_gamma, beta, mean_in, var_in, logdet_in, eps, training, reverse, reduce_fn, count):
+    def forward(ctx, x, log_gamma, beta, mean_in, var_in, logdet_in, eps, training, reverse, reduce_fn, count,
+                moments=None):
         ctx.set_materialize_grads(False)
         dev = check_device(x, log_gamma, beta, mean_in, var_in, logdet_in)
         B, F = x.shape
         y = torch.empty_like(x)
         ld = torch.empty((B,), dtype=x.dtype, device=dev)
-        stats = torch.empty((_lib.load().vae_bnflow_stats_floats(F),), dtype=torch.float32, device=dev)
+        # `moments`: a stats buffer in which the MADE tail that produced x has already left x's column moments
+        stats = moments if moments is not None else \
+            torch.empty((_lib.load().vae_bnflow_stats_floats(F),), dtype=torch.float32, device=dev)
         lg32, b32 = log_gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         sync = bool(training) and reduce_fn is not None and count is not None
         with _Guard(dev):
@@ -1344,8 +1368,8 @@ class _BNFlow(torch.autograd.Function):
                 gvar = pack[F:2 * F] / count - gmean * gmean + eps
                 mean_in, var_in = gmean.float().contiguous(), gvar.float().contiguous()
             call('vae_bnflow_fwd', ptr(x), ptr(lg32), ptr(b32), ptr(mean_in), ptr(var_in), ptr(stats), ptr(y),
-                 ptr(logdet_in), ptr(ld), B, F, eps, int(training and not sync), int(reverse), dtype_code(x),
-                 stream_ptr(dev))
+                 ptr(logdet_in), ptr(ld), B, F, eps, (2 if moments is not None else 1) if (training and not sync) else 0,
+                 int(reverse), dtype_code(x), stream_ptr(dev))
         ctx.save_for_backward(x, lg32, stats)
         ctx.cfg = (training, reverse, logdet_in is not None, log_gamma.dtype, reduce_fn if sync else None, count)
         ctx.mark_non_differentiable(stats)
@@ -1377,7 +1401,7 @@ class _BNFlow(torch.autograd.Function):
                      dtype_code(x), stream_ptr(dev))
         g_beta = sums[:F].to(pdt)
         g_lg = (torch.exp(lg32) * sums[F:2 * F] + sums[2 * F]).to(pdt)
-        return gx, g_lg, g_beta, None, None, (gld if has_ld else None), None, None, None, None, None
+        return gx, g_lg, g_beta, None, None, (gld if has_ld else None), None, None, None, None, None, None
 
 
 class _ActNorm(torch.autograd.Function):
@@ -1435,7 +1459,7 @@ def actnorm(x, weight, bias, logdet_in=None):
 
 
 def bnflow(x, log_gamma, beta, running_mean=None, running_var=None, logdet_in=None, eps=1e-5, training=True,
-           reverse=False, reduce_fn=None, count=None):
+           reverse=False, reduce_fn=None, count=None, moments=None):
     """BatchNormFlow 'direct' (flows/__init__.py:233-257), optionally with the Reverse that follows it in a
     MAF block folded into the store.  Returns (y [B, F], logdet_out [B], batch_mean [F], batch_var [F]) --
     the last two are what the caller folds into its running statistics (:240-246).  With `reduce_fn` and `count`
@@ -1448,6 +1472,8 @@ def bnflow(x, log_gamma, beta, running_mean=None, running_var=None, logdet_in=No
         raise ValueError("bnflow: the parameter vectors must have x.shape[1] = %d entries" % F)
     mi = None if training else running_mean.float().contiguous()
     vi = None if training else running_var.float().contiguous()
+    if moments is not None and (not training or reduce_fn is not None):
+        moments = None      # only the plain training forward takes its statistics from the producer's launch
     y, ldo, stats = _BNFlow.apply(x, log_gamma, beta, mi, vi, ld, float(eps), bool(training), bool(reverse),
-                                  reduce_fn, count)
+                                  reduce_fn, count, moments)
     return y, ldo, stats[:F], stats[F:2 * F]
