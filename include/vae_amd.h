@@ -54,7 +54,8 @@ enum { VAE_NLL_BERNOULLI = 0, VAE_NLL_GAUSSIAN = 1, VAE_NLL_DISC_LOGISTIC = 2 };
 
 /* ABI version of this header; bumped on any signature change. */
 int vae_abi_version(void);
-/* Bytes of scratch every entry point that takes `workspace` may use. */
+/* Bytes of scratch every entry point that takes `workspace` may use (ABI v11: 68 KiB of counters and block partials
+ * + 4 MiB of per-chunk row sums for the long-row one-pass NLL = 4 263 936 bytes). */
 size_t vae_workspace_bytes(void);
 /* Tuning hook (no reference counterpart; scripts/ab.py): overrides one launch-geometry choice for the calls that
  * follow, process-wide.  name: "G", "U", "MAXGRID", "REDUCEGRID" (the VAE_AMD_<name> environment variables set the same knobs
@@ -308,8 +309,9 @@ int vae_nll_elbo_fused(const void* x, const void* recon, int nll_type, const voi
 int vae_nll_fused_grad_finish(void* grecon, const float* gmeans, int64_t n, int dtype, vae_stream_t stream);
 /* vae_nll_elbo_fused for callers that cannot allocate or keep a workspace (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc): the same kernels, with the scratch they need -- the closing
- * launch's arrival counters and block partials, vae_workspace_bytes() = 68 KiB -- in a file-scope __device__ array
- * of the library instead of a caller buffer.  No counterpart in the reference.  The call allocates and frees
+ * launch's arrival counters and block partials, 68 KiB (the first 17408 floats of what a caller's workspace holds;
+ * the per-chunk row sums that vae_nll_elbo_fused keeps behind them for long rows are not needed: this entry point
+ * runs long rows a block per row) -- in a file-scope __device__ array of the library instead of a caller buffer.  No counterpart in the reference.  The call allocates and frees
  * nothing; every GPU the library is used on holds its own copy of the array until the process ends.  Arguments as
  * vae_nll_elbo_fused without `workspace`; the device that owns `stream` must be the current device.  B up to
  * VAE_STATIC_MAX_ROWS, beyond it VAE_ERR_ARG.  All calls on one GPU share that GPU's array: calls that overlap in

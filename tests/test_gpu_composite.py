@@ -814,7 +814,15 @@ def test_config4_chain_full_size():
     Checked: the chain's sample, logdet and KL against the CPU oracle with the same weights and noise; the loss
     dict's size-independent properties (elbo == nll + kld per sample, means == means of the vectors); and shard
     invariance of every per-sample output in eval mode (batch statistics make training-mode shards differ by
-    construction: vae_amd.dist reduces them, tests/test_gpu_dist.py)."""
+    construction: vae_amd.dist reduces them, tests/test_gpu_dist.py).
+
+    Tolerances: the chain comparison is rtol 1e-4 (atol 1e-3 on z, 1e-2 on the logdet, 5e-2 on a KL of magnitude
+    ~1e3), not 1e-5, because fifteen stock masked GEMMs with K = 256 (hipBLASLt on the GPU, MKL on the CPU: different
+    summation orders, then amplified by exp(-a) and the batch-norm division) sit between the kernels; that looseness is
+    the GEMMs', not the kernels'.  The kernels' own share is held tighter elsewhere: the Gaussian KL of this very chain
+    to torch.equal (end of this test), the Gaussian draw bit for bit (test_sequential_gauss_flow_golden_end_to_end),
+    the MADE / BatchNormFlow / Reverse tails at rtol 1e-5 with their inputs given (tests/test_gpu_flowtail.py, also
+    the folded MADE + moments launch this chain takes in training), the Flow KL at 1e-5 (tests/test_gpu_flow.py)."""
     from vae_amd.reparameterizers import SequentialReparameterizer
     from vae_amd import elbo as E
     torch.manual_seed(4)

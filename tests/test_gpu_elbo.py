@@ -297,6 +297,34 @@ def test_fused_backward_bf16_and_no_grad(half):
     assert not r['loss_mean'].requires_grad
 
 
+def test_fused_gradient_buffer_lifetime():
+    """The one-pass loss keeps a [B, D] gradient buffer from forward to backward.  It must not exist without a graph
+    (no_grad / inference_mode: validation loops), must go when the outputs are dropped without a backward, and is
+    handed out -- not copied -- by the backward."""
+    from vae_amd import elbo as E
+    torch.manual_seed(8)
+    B, D = 4096, 3 * 32 * 32
+    x = torch.rand(B, 3, 32, 32, device=DEV)
+    recon = torch.randn(B, 3, 32, 32, device=DEV, requires_grad=True)
+    nbytes = B * D * 4
+    E.loss_function(recon, x, None, 'bernoulli')     # the workspace and the scalar cells exist from here on
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    for ctxmgr in (torch.no_grad, torch.inference_mode):
+        with ctxmgr():
+            out = E.loss_function(recon, x, None, 'bernoulli')
+        assert torch.cuda.memory_allocated() - base < nbytes // 2, ctxmgr
+        del out
+    out = E.loss_function(recon, x, None, 'bernoulli')
+    assert torch.cuda.memory_allocated() - base >= nbytes          # the stored d loss_mean / d recon
+    out = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}   # what a logging loop keeps
+    assert torch.cuda.memory_allocated() - base < nbytes // 2       # graph gone -> buffer gone
+    out = E.loss_function(recon, x, None, 'bernoulli')
+    (g,) = torch.autograd.grad(out['loss_mean'], recon)
+    del out
+    assert torch.cuda.memory_allocated() - base < nbytes + nbytes // 2   # g IS the buffer: no second [B, D] tensor
+
+
 def test_autoencoder_and_nokl_losses():
     """autoencoder.py:12-32, :92-115: NLL-only objectives (dict schema of the reference, values vs the oracle)."""
     from vae_amd.elbo import AutoencoderMixin, VAENoKLMixin

@@ -77,8 +77,15 @@ def test_graph_capture_gaussian_elbo_step():
     vae_amd.rng.manual_seed(11)
     graph.replay()
     assert torch.equal(z, za) and not torch.equal(za, zb)
-    # no draw was materialised: the graph holds no torch.randn node's [B, L] buffer (the draw is in-kernel)
-    assert len(vae_amd.rng._cells) >= 1
+    # no draw was materialised: the graph holds no torch.randn node's [B, L] buffer (the draw is in-kernel); its
+    # offset word comes from the per-device pool that the warm-up steps allocated OUTSIDE the capture, and the pool
+    # hands its words out again after release_captured()
+    pool = vae_amd.rng._pools[torch.cuda.current_device()]
+    assert pool[1] >= 1 and not vae_amd.rng._cells
+    used = pool[1]
+    del graph
+    vae_amd.rng.release_captured()
+    assert pool[1] == 0 and used <= vae_amd.rng._POOL_WORDS
 
 
 def test_graph_capture_gumbel_and_vrnn_pair():

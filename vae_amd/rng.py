@@ -6,14 +6,34 @@ torch/distributions/relaxed_bernoulli.py:105).  The kernels instead key Philox4x
 call counter that restarts whenever the seed changes, so `torch.manual_seed(s)` still makes a
 run reproducible, and a sample's noise does not depend on how the batch is sharded over ranks.
 Draws recorded into a HIP graph read their offset from a device word instead (_captured_offset).
-For parity tests noise is injected explicitly and none of this is used.
+The SEED of a captured draw is a host value recorded into the graph: `manual_seed(new)` after a capture restarts the
+device counter (so a replayed run is reproducible) but replays keep the seed they were captured with -- re-capture to
+reseed.  For parity tests noise is injected explicitly and none of this is used.
 """
 import torch
 
 _state = {'seed': None, 'offset': 0}
 OFFSET_ON_DEVICE = 1 << 63      # VAE_OFFSET_ON_DEVICE (include/vae_amd.h)
-_cells = []                     # the device words of captured draws: alive as long as the graphs that read them
+_POOL_WORDS = 1 << 16           # captured draws per device between two release_captured() calls (512 KiB)
+_pools = {}                     # device index -> [int64 tensor allocated OUTSIDE any capture, next free word]
+_cells = []                     # fallback words allocated under capture (no eager call came first on that device)
 _graph_devices = set()
+
+
+def _pool(dev, create):
+    p = _pools.get(dev.index)
+    if p is None and create:
+        p = _pools[dev.index] = [torch.zeros(_POOL_WORDS, dtype=torch.int64, device=dev), 0]
+    return p
+
+
+def release_captured():
+    """Hand back the device words of every captured draw.  Call it after the graphs that were captured so far have
+    been deleted (a model that re-captures on every shape change would otherwise run out of the 65536 words a device
+    holds); graphs that are still alive would share words with later captures."""
+    for p in _pools.values():
+        p[1] = 0
+    del _cells[:]
 
 
 def _captured_offset(n):
@@ -24,11 +44,22 @@ def _captured_offset(n):
     import ctypes
     from ._lib import call, stream_ptr
     dev = torch.device('cuda', torch.cuda.current_device())
-    cell = torch.empty(1, dtype=torch.int64, device=dev)
-    _cells.append(cell)
+    p = _pool(dev, create=False)
+    if p is None:
+        # no eager draw ran on this device before the capture (torch asks for warm-up steps, which create the pool):
+        # a word from the graph's own memory pool, kept alive here
+        cell = torch.empty(1, dtype=torch.int64, device=dev)
+        _cells.append(cell)
+        address = cell.data_ptr()
+    else:
+        if p[1] >= _POOL_WORDS:
+            raise RuntimeError("vae_amd.rng: %d captured draws on cuda:%d; delete the old graphs and call "
+                               "vae_amd.rng.release_captured()" % (_POOL_WORDS, dev.index))
+        address = p[0].data_ptr() + 8 * p[1]
+        p[1] += 1
     _graph_devices.add(dev.index)
-    call('vae_rng_next', ctypes.c_void_p(cell.data_ptr()), int(n), stream_ptr(dev))
-    return OFFSET_ON_DEVICE | cell.data_ptr()
+    call('vae_rng_next', ctypes.c_void_p(address), int(n), stream_ptr(dev))
+    return OFFSET_ON_DEVICE | address
 
 
 def next_calls(n):
@@ -39,6 +70,8 @@ def next_calls(n):
     if seed != _state['seed']:
         _state['seed'] = seed
         _state['offset'] = 0
+    if torch.cuda.is_available():
+        _pool(torch.device('cuda', torch.cuda.current_device()), create=True)   # outside any capture
     first = _state['offset'] + 1
     _state['offset'] += n
     return seed, first
