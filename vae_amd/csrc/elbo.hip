@@ -230,6 +230,7 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_fused_kernel(
   for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
     const int64_t row = t * rpb + rloc;
     float s = 0.f;
+    f32x2 s2 = {0.f, 0.f};   // Bernoulli: the packed pair of partial sums (nll_bern_value_grad)
     // the [B] inputs of the row epilogue, requested with the row itself (behind the row sum they were a dependent
     // round trip with nothing else of the wave in flight)
     float k = 0.f, ad = 0.f, m = 0.f;
@@ -254,18 +255,9 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_fused_kernel(
           const int j = j0 + u * G;
           if (j < nvec) {
             float ga[V], gb[V];
+            if constexpr (NLL == VAE_NLL_BERNOULLI) nll_bern_value_grad<V>(xv[u], a[u], cscale, s2, ga);
 #pragma unroll
             for (int i = 0; i < V; ++i) {
-              if constexpr (NLL == VAE_NLL_BERNOULLI) {
-                // one exp serves both: softplus(-|l|) for the value, sigmoid(l) for the gradient
-                const float l = a[u][i];
-                const float e = fast_exp(-fabsf(l));
-                const float r = fast_rcp(1.0f + e);
-                s += fmaxf(l, 0.0f) - l * xv[u][i] + fast_log(1.0f + e);
-                // sigmoid(l) - x without cancellation at x = 1: for l >= 0 use (1 - x) - (1 - sigmoid) = (1 - x) - e r
-                const float er = e * r;
-                ga[i] = cscale * (l >= 0.0f ? (1.0f - xv[u][i]) - er : er - xv[u][i]);
-              }
               if constexpr (NLL == VAE_NLL_GAUSSIAN) {
                 s += nll_gauss(xv[u][i], a[u][i], b[u][i]);
                 nll_gauss_grad(xv[u][i], a[u][i], b[u][i], ga[i], gb[i]);
@@ -283,6 +275,7 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_fused_kernel(
         }
       }
     }
+    if constexpr (NLL == VAE_NLL_BERNOULLI) s = s2[0] + s2[1];
     s = row_sum(s, G);
     if (row < B && sub == 0) {
       const float n = to_f32(from_f32<T>(s));
@@ -316,6 +309,7 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_fused_chunk_kernel(
     T* gr = grecon + row * rstride;
     const int j0 = threadIdx.x + chunk * kBlock * U;
     float s = 0.f;
+    f32x2 s2 = {0.f, 0.f};
     float xv[U][V], a[U][V], b[U][V];
     load_chunk<T, V, U, kNtNllFwd>(xr, j0, kBlock, nvec, xv);
     load_chunk<T, V, U, kNtNllFwd>(rr, j0, kBlock, nvec, a);
@@ -325,16 +319,9 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_fused_chunk_kernel(
       const int j = j0 + u * kBlock;
       if (j < nvec) {
         float ga[V], gb[V];
+        if constexpr (NLL == VAE_NLL_BERNOULLI) nll_bern_value_grad<V>(xv[u], a[u], cscale, s2, ga);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-          if constexpr (NLL == VAE_NLL_BERNOULLI) {
-            const float l = a[u][i];
-            const float e = fast_exp(-fabsf(l));
-            const float r = fast_rcp(1.0f + e);
-            s += fmaxf(l, 0.0f) - l * xv[u][i] + fast_log(1.0f + e);
-            const float er = e * r;
-            ga[i] = cscale * (l >= 0.0f ? (1.0f - xv[u][i]) - er : er - xv[u][i]);
-          }
           if constexpr (NLL == VAE_NLL_GAUSSIAN) {
             s += nll_gauss(xv[u][i], a[u][i], b[u][i]);
             nll_gauss_grad(xv[u][i], a[u][i], b[u][i], ga[i], gb[i]);
@@ -350,6 +337,7 @@ __global__ __launch_bounds__(kBlock) void nll_elbo_fused_chunk_kernel(
         if constexpr (NLL != VAE_NLL_BERNOULLI) store_vec<T, V>(nts, gr + D + (int64_t)j * V, gb);
       }
     }
+    if constexpr (NLL == VAE_NLL_BERNOULLI) s = s2[0] + s2[1];
     s = row_sum(s, kBlock);
     if (threadIdx.x == 0) parts[tc] = s;
   }

@@ -30,6 +30,59 @@ __device__ __forceinline__ float nll_bern(float x, float l) {
 }
 __device__ __forceinline__ float nll_bern_grad(float x, float l) { return fast_rcp(1.0f + __expf(-l)) - x; }
 
+// Value AND gradient of V elements (V even), for the one-pass kernels.  At 2 bytes per element those are no longer
+// HBM-bound but co-bound by VALU issue (r03: 406 instructions per wave, ~25 per element), so the arithmetic is laid
+// out for the packed-fp32 pipe (v_pk_add / v_pk_mul / v_pk_fma_f32: two elements per lane and instruction):
+//   e = exp(-|l|), p = 1 + e, r = 1/p, pos = [sign bit of l clear], d = pos - x
+//   value    = max(l,0) - l x + log1p(e) = l d + ln2 log2(p)                         (two packed fma into the sum)
+//   gradient = sigmoid(l) - x            = d - copysign(e r, l)    (l >= 0: (1 - x) - e r; l < 0: e r - x: no
+//                                                                   cancellation at x = 1, as before)
+// One exponential serves both; `pos` and the copysign both read the SIGN BIT of l, so l = -0.0 is consistent
+// (pos = 0, -e r = -1/2: gradient 1/2 - x).  Per element: 3 quarter-rate transcendentals + ~10 full-rate
+// instruction slots (was ~22).  `s2` carries two partial sums (even / odd elements), added by the caller.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int V>
+__device__ __forceinline__ void nll_bern_value_grad(const float (&x)[V], const float (&l)[V], float cscale, f32x2& s2,
+                                                    float (&g)[V]) {
+  static_assert(V == 1 || V % 2 == 0, "pairs, or the scalar fallback kernels' single element");
+  if constexpr (V == 1) {
+    const float e = __builtin_amdgcn_exp2f(-fabsf(l[0]) * kLog2e), p = 1.0f + e;
+    const float d = (__builtin_bit_cast(int, l[0]) < 0 ? 0.0f : 1.0f) - x[0];
+    s2[0] = __builtin_fmaf(kLn2, __builtin_amdgcn_logf(p), __builtin_fmaf(l[0], d, s2[0]));
+    g[0] = (d - __builtin_copysignf(e * __builtin_amdgcn_rcpf(p), l[0])) * cscale;
+    return;
+  }
+  const f32x2 one = {1.0f, 1.0f}, ln2 = {kLn2, kLn2}, cs = {cscale, cscale};
+#pragma unroll
+  for (int i = 0; i + 1 < V; i += 2) {
+    const f32x2 lv = {l[i], l[i + 1]}, xv = {x[i], x[i + 1]};
+    // (element-wise on the scalars, not through lv[k]: hipcc 7.2 folded `bit_cast<int>(lv[k]) < 0` of both halves
+    // into the compare of the LOW half -- op_sel_hi:[0,1] on the packed subtract -- and every odd element took its
+    // neighbour's sign)
+    const float p0 = __builtin_bit_cast(int, l[i]) < 0 ? 0.0f : 1.0f;
+    const float p1 = __builtin_bit_cast(int, l[i + 1]) < 0 ? 0.0f : 1.0f;
+    const f32x2 pos = {p0, p1};
+    const f32x2 e = {__builtin_amdgcn_exp2f(-fabsf(l[i]) * kLog2e), __builtin_amdgcn_exp2f(-fabsf(l[i + 1]) * kLog2e)};
+    const f32x2 p = one + e;
+    f32x2 r, lg;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      r[k] = __builtin_amdgcn_rcpf(p[k]);
+      lg[k] = __builtin_amdgcn_logf(p[k]);
+    }
+    const f32x2 er = e * r;
+    const f32x2 d = pos - xv;
+    s2 = __builtin_elementwise_fma(lv, d, s2);
+    s2 = __builtin_elementwise_fma(ln2, lg, s2);
+    f32x2 ser;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) ser[k] = __builtin_copysignf(er[k], lv[k]);
+    const f32x2 gg = (d - ser) * cs;
+    g[i] = gg[0];
+    g[i + 1] = gg[1];
+  }
+}
+
 // NLL == VAE_NLL_GAUSSIAN: -Normal(m, softplus(v) + 1e-6).log_prob(x)
 __device__ __forceinline__ float nll_gauss(float x, float m, float v) {
   const float s = softplusf_(v) + 1e-6f;
