@@ -91,7 +91,8 @@ def configs_block():
     bc.concat_module(65536, 128, 256)          # C3
     bc.c4_module(8192)                         # C4
     bc.vrnn_sequence(64, 4096, 128)            # C5
-    keep = ('concat step (eager)', 'concat step (HIP graph)', 'c4 latent chain (module)', 'c4 loss (module)',
+    keep = ('concat step (eager)', 'concat step (HIP graph)', 'c4 latent chain (module)', 'c4 latent chain (HIP graph)',
+            'c4 loss (module)',
             'vrnn sequence (eager)', 'vrnn sequence (HIP graph)')
     tag = {'concat': 'configs[2] C3', 'c4': 'configs[3] C4', 'vrnn': 'configs[4] C5'}
     out = []

@@ -388,10 +388,34 @@ def c4_module(B, L=128, F=256, C=3, H=64, W=64):
             p.grad = None
     # our kernels on the chain: gauss fwd 12L+4 / bwd 20L+4; per MAF block made tail 16F+4 / 24F+4 and BatchNormFlow
     # 12F+8 / 20F+4; flow KL 4F+8 / 8F
-    chain_bytes = B * ((12 * L + 4) + (20 * L + 4) + 5 * ((16 * Fw + 4) + (24 * Fw + 4) + (12 * Fw + 8) + (20 * Fw + 4))
+    # (r03: the MADE tail leaves the BatchNormFlow moments: 8F+8 forward instead of 12F+8)
+    chain_bytes = B * ((12 * L + 4) + (20 * L + 4) + 5 * ((16 * Fw + 4) + (24 * Fw + 4) + (8 * Fw + 8) + (20 * Fw + 4))
                        + (4 * Fw + 8) + 8 * Fw)
-    timeit('c4 latent chain (module)', 'B=%d Gaussian L=%d -> dense -> 5 x (MADE, BatchNormFlow, Reverse) F=%d, fwd+kl+bwd; '
-           'bytes = the tails and KLs only, time includes the stock masked GEMMs' % (B, L, Fw), chain, chain_bytes)
+    what = ('B=%d Gaussian L=%d -> dense -> 5 x (MADE, BatchNormFlow, Reverse) F=%d, fwd+kl+bwd; bytes = the tails and '
+            'KLs only, time includes the stock masked GEMMs' % (B, L, Fw))
+    timeit('c4 latent chain (module)', what, chain, chain_bytes)
+    # the same chain as ONE HIP graph (eager it is ~150 launches from Python).  Fresh leaves: a leaf that first
+    # accumulated its gradient on the default stream would pull that stream into the capture.
+    import copy
+    m2 = copy.deepcopy(m)
+    lg2 = logits.detach().clone().requires_grad_(True)
+    leaves = [lg2] + [p for p in m2.parameters() if p.requires_grad]
+
+    def chain2():
+        z, params = m2(lg2)
+        return torch.autograd.grad([z, m2.kl(params)], leaves, [gzf, gkl], allow_unused=True)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            chain2()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        keep = chain2()
+    timeit('c4 latent chain (HIP graph)', what, graph.replay, chain_bytes)
+    del graph, keep
     kld = T(B, kind='rand')
 
     def loss():
