@@ -330,3 +330,57 @@ def test_concat_row_kernel():
             assert torch.equal(z1[:, L:].cpu() == 1, z0[:, L:] == 1)
         close(k1, k0, rtol=1e-5, atol=1e-3)
         close(g1, g0, rtol=1e-4, atol=1e-5)
+
+
+def test_made_tail_with_moments_then_bnflow():
+    """The MADE tail that also leaves the BatchNormFlow moments (its u store takes the nt branch) followed by the
+    moments-given BatchNormFlow forward + Reverse, against the oracle's two layers."""
+    from vae_amd import functional as F_
+    torch.manual_seed(10)
+    B, Fd = big(16400, 512)
+    x, ma = torch.randn(B, Fd) * 1.5 + 0.7, torch.randn(B, 2 * Fd) * 0.6
+    lg, beta = torch.randn(Fd) * 0.3, torch.randn(Fd)
+    wu, wl = torch.randn(B, Fd), torch.randn(B)
+    c = [t.clone().requires_grad_(True) for t in (x, ma, lg, beta)]
+    u0, ld0 = O.made_tail(c[0], c[1][:, :Fd], c[1][:, Fd:])
+    y0, lb0, mean0, var0 = O.bnflow(u0, c[2], c[3], None, None, training=True)
+    y0 = O.reverse_columns(y0)
+    l0 = ld0.view(-1) + lb0
+    g0 = torch.autograd.grad((y0 * wu).sum() + (l0 * wl).sum(), c)
+    d = [t.to(DEV).requires_grad_(True) for t in (x, ma, lg, beta)]
+    stats = F_.bn_stats_buffer(d[0])
+    assert stats is not None
+    u1, ld1 = F_.made_tail(d[0], d[1], None, bn_stats=stats)
+    y1, l1, mean1, var1 = F_.bnflow(u1, d[2], d[3], logdet_in=ld1, training=True, reverse=True, moments=stats)
+    g1 = torch.autograd.grad((y1 * wu.to(DEV)).sum() + (l1 * wl.to(DEV)).sum(), d)
+    close(u1, u0, rtol=1e-5, atol=1e-6)
+    close(mean1, mean0, rtol=1e-5, atol=1e-6)
+    close(var1, var0, rtol=2e-5, atol=1e-6)
+    close(y1, y0, rtol=1e-4, atol=2e-5)
+    close(l1, l0, rtol=1e-5, atol=1e-3)
+    close(g1[0], g0[0], rtol=1e-3, atol=1e-5)
+    close(g1[1], g0[1], rtol=1e-3, atol=1e-5)
+    close(g1[2], g0[2], rtol=1e-3, atol=2e-2)
+    close(g1[3], g0[3], rtol=1e-4, atol=1e-3)
+
+
+def test_gauss_4d_logits():
+    """4-D logits read where they are (channel halves, KL over W): [B, C, H, W] with the sample tensor >= 32 MiB."""
+    from vae_amd.reparameterizers import IsotropicGaussian
+    torch.manual_seed(11)
+    B, C, H, W = 520, 64, 16, 32         # z: [520, 32, 16, 32] = 34 MB
+    assert B * (C // 2) * H * W * 4 >= NT
+    logits, noise = torch.randn(B, C, H, W), torch.randn(B, C // 2, H, W)
+    w = torch.randn(B, C // 2, H, W)
+    lc = logits.clone().requires_grad_(True)
+    z0, p0 = O.gauss_forward(lc, noise)
+    k0 = O.gauss_kl(p0)
+    (g0,) = torch.autograd.grad((z0 * w).sum() + k0.sum(), lc)
+    m = IsotropicGaussian({'continuous_size': C, 'cuda': True, 'half': False}).train()
+    ld = logits.to(DEV).requires_grad_(True)
+    z1, p1 = m(ld, noise=noise.to(DEV))
+    k1 = m.kl(p1)
+    (g1,) = torch.autograd.grad((z1 * w.to(DEV)).sum() + k1.sum(), ld)
+    assert z1.shape == z0.shape and torch.equal(z1.detach().cpu(), z0.detach())
+    close(k1, k0, rtol=1e-5, atol=1e-4)
+    close(g1, g0, rtol=1e-4, atol=1e-5)
