@@ -141,9 +141,15 @@ def main():
     dev = torch.device('cuda', local_rank % max(ndev, 1))
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1: take the N > 1 code path (process group, async all-reduces, strong leg) with a single rank --
+    # the only way to run the RCCL side of this file on a one-GPU box (torch.distributed.run --nproc-per-node 1)
+    if world > 1 or os.environ.get('BENCH_FORCE_DIST', '0') == '1':
         import torch.distributed as dist
         if backend == 'nccl':
+            # the collective's stream at high priority: its one small kernel is then scheduled beside a backward launch
+            # that fills every CU instead of behind it (one rank under RCCL, scripts/rccl_one_rank.sh: step 0.348 ->
+            # 0.340 ms with the all-reduce overlapped mid-step; 0.325 without any collective, 0.337 synchronous)
+            os.environ.setdefault('TORCH_NCCL_HIGH_PRIORITY', '1')
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
@@ -201,7 +207,12 @@ def main():
          'elbo': elbo, 'scalars': scalars, 'gmeans': gmeans, 'grecon': grecon, 'gkld': gkld, 'glogits': glogits,
          'pmeans': pmeans, 'dt': 0}        # what step() runs on: swapped for the 16-bit variant below
 
+    solo = world == 1 and dist is None        # the single-process extras (variants, graph captures, configs, CPU leg)
     overlap = dist is not None and backend == 'nccl' and os.environ.get('BENCH_SYNC_ALLREDUCE', '0') != '1'
+    # BENCH_ALLREDUCE=deferred: the collective is enqueued at the END of the step on a copy of the scalars and joined
+    # at the end of the NEXT step (no cross-stream event in the middle of a step; a whole step to complete in)
+    deferred = overlap and os.environ.get('BENCH_ALLREDUCE', 'midstep') == 'deferred'
+    scal_copy = torch.zeros_like(scalars)
     pending = [None]
     step_no = [1]   # Philox call offset: a fresh draw every step, the same one in that step's backward
     rng_cell = [None]   # graph replay with in-kernel draws: the offset lives in this device word (vae_rng_next)
@@ -230,7 +241,9 @@ def main():
             # global-batch means (abstract_vae.py:381-387) in one 8-float message.  Nothing later in the step reads
             # them (the kernels pre-scale by 1/B_global), so over RCCL the collective runs on its own stream beside
             # the backward kernels and is joined at the end of the step.
-            if overlap:
+            if deferred:
+                pass
+            elif overlap:
                 pending[0] = dist.all_reduce(T['scalars'], op=dist.ReduceOp.SUM, async_op=True)
             else:
                 all_reduce(T['scalars'])
@@ -248,6 +261,9 @@ def main():
         if pending[0] is not None:
             pending[0].wait()                 # the launch stream waits for the collective; no host block
             pending[0] = None
+        if deferred:
+            scal_copy.copy_(T['scalars'].float())   # behind the wait: the previous collective is done with scal_copy
+            pending[0] = dist.all_reduce(scal_copy, op=dist.ReduceOp.SUM, async_op=True)
         step_no[0] += 1
 
     for _ in range(args.warmup):
@@ -294,7 +310,10 @@ def main():
     # under profiles/ for comparison)
     import statistics
     dur_ms = {n: statistics.median(e[a].elapsed_time(e[b]) for e in timed) for n, (a, b) in seg.items()}
-    sanity = float(scalars[0].item())
+    if pending[0] is not None:
+        pending[0].wait()
+        pending[0] = None
+    sanity = float((scal_copy if deferred else scalars)[0].item())
     if not (sanity == sanity):
         raise SystemExit('bench: loss_mean is NaN')
 
@@ -324,7 +343,7 @@ def main():
     # the production form of the same step (the module classes' default): eps drawn inside the kernels from
     # Philox4x32-10 instead of read from HBM -- reported beside the main figure, never as `value`
     philox_variant = None
-    if world == 1 and not philox and not args.main_only:
+    if solo and not philox and not args.main_only:
         noise_arg[0] = None
         for _ in range(args.warmup):
             step()
@@ -351,7 +370,7 @@ def main():
     # the same step on bf16 tensors (north_star's second element type; arithmetic stays fp32 inside the kernels):
     # reported beside the figure, never as `value` (BASELINE.json's metric is the fp32 step)
     bf16_variant = None
-    if world == 1 and not philox and not args.main_only and not args.materialize_logvar:
+    if solo and not philox and not args.main_only and not args.materialize_logvar:
         keep = dict(T)
         for k in ('logits', 'noise', 'x', 'recon', 'gz'):
             T[k] = keep[k].to(torch.bfloat16)
@@ -386,7 +405,7 @@ def main():
     # cost.  Once with the injected noise, once with in-kernel Philox draws whose call offset lives in a device word
     # that a one-thread node of the graph advances (vae_rng_next), so every replay draws fresh noise.
     graph_replay = None
-    if world == 1 and not philox and not args.main_only:
+    if solo and not philox and not args.main_only:
         graph_replay = {}
         side = torch.cuda.Stream(device=dev)
         cell = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -418,7 +437,7 @@ def main():
     # the same step through the drop-in classes (autograd Functions, torch allocator): not the timed region,
     # reported beside it so the cost of the Python boundary is visible
     module_path = None
-    if world == 1 and not args.main_only:
+    if solo and not args.main_only:
         from vae_amd.reparameterizers import IsotropicGaussian
         from vae_amd.elbo import loss_function
         mod = IsotropicGaussian({'continuous_size': 2 * L, 'cuda': True, 'half': False})
@@ -450,7 +469,7 @@ def main():
     # 158-170 through torch.distributions; abstract_vae.py:356-387; Bernoulli-with-logits NLL), same resident inputs
     # and injected noise: what the reference does on an MI355X without this library.  Reported beside the figure.
     stock_torch = None
-    if world == 1 and not args.main_only:
+    if solo and not args.main_only:
         stock_torch = stock_torch_step_rate(logits, noise, x.view(B, C, H, W), recon.view(B, C, H, W), gz)
 
     if rank == 0:
@@ -512,9 +531,9 @@ def main():
             'stock_torch_same_gpu': stock_torch,
             'graph_replay': graph_replay,
         }
-        if world == 1 and not args.main_only and not args.no_configs:
+        if solo and not args.main_only and not args.no_configs:
             out['configs'] = configs_block()
-        if world == 1 and not args.no_cpu_baseline and not args.main_only:
+        if solo and not args.no_cpu_baseline and not args.main_only:
             out['cpu_baseline'] = cpu_baseline()
             # BASELINE.json configs[0], the designated CPU configuration: latent 32
             out['cpu_baseline_c1'] = cpu_baseline(seconds=6.0, L=32, label='configs[0] shapes')
@@ -624,7 +643,8 @@ def whole_model_leg(dev, x_img, B, world, fence, all_reduce_max, steps=10, warmu
               'cuda': True, 'half': False, 'continuous_mut_info': 0, 'discrete_mut_info': 0}
     torch.manual_seed(0)                       # the same initial weights on every rank
     model = SimpleVAE(config).to(dev).train()
-    if world > 1:
+    many = world > 1 or all_reduce_max is not None     # (a forced one-rank group: BENCH_FORCE_DIST)
+    if many:
         vdist.configure(model, global_batch)
     # BENCH_GRAD_BUCKETS=n: n pieces, each sent as soon as backward has filled it (default: one message after backward;
     # 6.4 MB is latency-bound on xGMI either way)
@@ -634,7 +654,7 @@ def whole_model_leg(dev, x_img, B, world, fence, all_reduce_max, steps=10, warmu
     def wstep():
         recon, params = model(x_img)
         loss = model.loss_function(recon, x_img, params)
-        if world > 1:
+        if many:
             loss, _ = vdist.globalize_loss(loss)
         flat.zero()
         loss['loss_mean'].backward()
@@ -649,7 +669,7 @@ def whole_model_leg(dev, x_img, B, world, fence, all_reduce_max, steps=10, warmu
         last = wstep()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if many:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         all_reduce_max(t, op=tdist.ReduceOp.MAX)
         dt = float(t.item())

@@ -21,8 +21,19 @@ exactly what the 1-rank run draws for the same rows.
 
 Works on any torch.distributed backend: "nccl" (= RCCL on ROCm) on GPUs, "gloo" in the CPU tests.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def _many(group=None):
+    """True when collectives have to run: an initialised process group of more than one rank -- or of exactly one with
+    VAE_AMD_DIST_FORCE=1, which sends every collective of this module through the backend anyway (the only way to run
+    the RCCL side on a one-GPU box: stream waits, async work objects and hooks are the same with one rank)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get('VAE_AMD_DIST_FORCE', '0') == '1'
 
 
 def shard_rows(global_batch, rank=None, world_size=None):
@@ -62,7 +73,7 @@ class _AllReduceSum(torch.autograd.Function):
 def packed_all_reduce(tensors, group=None):
     """All-reduce(sum) several small tensors as ONE message; returns tensors of the original shapes.
     A no-op (identity) when torch.distributed is not initialised or the world is one rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _many(group):
         return list(tensors)
     flat = torch.cat([t.reshape(-1).float() for t in tensors])
     flat = _AllReduceSum.apply(flat, group)
@@ -76,7 +87,7 @@ def packed_all_reduce(tensors, group=None):
 
 def all_reduce_inplace(t, group=None):
     """reduce_fn for functional.flow_kl: in-place sum of a small float tensor over ranks."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _many(group):
         _sum_over_ranks_(t, group)
     return t
 
@@ -139,7 +150,7 @@ class FlatGradients(object):
         return self.flat.numel() * self.flat.element_size()
 
     def _distributed(self):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1
+        return _many(self._group)
 
     def _async_ok(self):
         # a gloo group reduces device tensors through the host, synchronously (see _sum_over_ranks_): at all_reduce()
