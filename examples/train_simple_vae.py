@@ -62,6 +62,7 @@ def main():
     torch.cuda.set_device(dev)
     if world > 1:
         if backend == 'nccl':
+            os.environ.setdefault('TORCH_NCCL_HIGH_PRIORITY', '1')   # small collectives beside full-chip launches
             torch.distributed.init_process_group('nccl', device_id=dev)
         else:
             torch.distributed.init_process_group(backend)
