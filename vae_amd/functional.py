@@ -853,6 +853,9 @@ class _ConcatLeaves(torch.autograd.Function):
         B, W_in = logits.shape
         rs = logits.stride(0)
         W_out = sum(s[1] for s in specs)
+        need = sum(2 * s[1] if s[0] == 'gauss' else s[1] for s in specs)
+        if W_in != need:      # the kernels index the row by the specs: a narrower row would be read past its end
+            raise ValueError("concat: logits have %d columns, the children consume %d" % (W_in, need))
         dt = dtype_code(logits)
         new = lambda *s: torch.empty(s, dtype=logits.dtype, device=dev)
         zcat = new(B, W_out)
