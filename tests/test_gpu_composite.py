@@ -138,7 +138,11 @@ def test_concat_row_kernel_matches_per_child_launches(B, L, K, train, dtype, inj
     from vae_amd import rng
     from vae_amd.reparameterizers import ConcatReparameterizer
     if dtype != torch.float32 and (L % 8 or K % 8):
-        pytest.skip('16-bit rows need multiples of 8 for the row kernel')
+        # 16-bit rows that are not whole 16-byte vectors: the row kernel must decline (the module then takes the
+        # per-child launches, which test_concat_fused_matches_per_child_path covers for these shapes)
+        probe = torch.empty(2, 2 * L + K, device=DEV, dtype=dtype)
+        assert not F_._row_kernel_ok(probe, (('gauss', L, 1e-6, None), ('gumbel', K, 1.0)))
+        return
     torch.manual_seed(B + L + K)
     c = cfg(continuous_size=2 * L, discrete_size=K)
     logits = torch.randn(B, 2 * L + K, device=DEV).to(dtype)
