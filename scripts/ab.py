@@ -29,7 +29,7 @@ z = torch.empty(B, L, **f32); logvar = torch.empty(B, L, **f32); kl = torch.empt
 nll = torch.empty(B, **f32); loss = torch.empty(B, **f32); elbo = torch.empty(B, **f32)
 scal = torch.zeros(8, device=dev); gmeans = torch.zeros(6, device=dev); gmeans[0] = 1
 grecon = torch.empty(B, D, **f32); gkld = torch.empty(B, **f32); glogits = torch.empty(B, 2 * L, **f32)
-ws = torch.zeros(1 << 18, device=dev)
+ws = torch.zeros(_lib.load().vae_workspace_bytes() // 4, device=dev)
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 
@@ -49,6 +49,7 @@ def kernels(lib):
         'gauss_fwd_nologvar': (lambda: lib.vae_gauss_reparam_kl_fwd(p(logits), 2 * L, p(noise), p(z), 0, None, p(kl), p(scal), p(ws), B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, DC, st), (4 * L * ES + ES) * B),
         'gauss_bwd': (lambda: lib.vae_gauss_reparam_kl_bwd(p(logits), 2 * L, p(noise), p(gz), 0, None, p(gkld), None, p(glogits), 0, B, L, 1e-6, 1.0 / (B * L), 1, 0, 0, 0, DC, st), (6 * L * ES + ES) * B),
         'nll_fwd': (lambda: lib.vae_nll_elbo_fwd(p(x), p(recon), 0, p(kl), None, None, 1.0, 1.0 / B, p(nll), p(loss), p(elbo), p(scal), p(ws), B, D, DC, st), (2 * D + 3) * ES * B),
+        'nll_fused': (lambda: lib.vae_nll_elbo_fused(p(x), p(recon), 0, p(kl), None, None, 1.0, 1.0 / B, 1.0, p(nll), p(loss), p(elbo), p(scal), p(ws), p(grecon), B, D, DC, st), (3 * D + 4) * ES * B),
         'nll_bwd': (lambda: lib.vae_nll_elbo_bwd(p(x), p(recon), 0, None, None, None, p(gmeans), 1.0, 1.0 / B, p(grecon), p(gkld), None, None, B, D, DC, st), 3 * D * ES * B),
     }
 
