@@ -52,3 +52,27 @@ def test_example_trains_two_ranks_gloo():
                          '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
                          os.path.join(ROOT, 'examples', 'train_simple_vae.py'), '--steps', '41', '--batch', '512'],
                         env=env))
+
+
+def test_bench_multi_rank_path_runs_under_rccl_with_one_rank():
+    """bench.py's N > 1 code path -- process group on RCCL, the per-step scalar all-reduce on the collective's stream
+    beside the backward launches, FlatGradients / globalize_loss in the whole-model leg, the strong leg's graph replay
+    + all-reduce on a copy -- with a single rank (BENCH_FORCE_DIST / VAE_AMD_DIST_FORCE): the one way to execute the
+    RCCL side on a one-GPU box.  The loss must equal the single-process step's (same seeds, same kernels)."""
+    import json
+    env = dict(os.environ, BENCH_FORCE_DIST='1', VAE_AMD_DIST_FORCE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    rc, out, err = _run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+                         '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+                         os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '5', '--warmup', '2', '--batch', '8192',
+                         '--no-cpu-baseline', '--no-configs'], env=env, timeout=150)
+    assert rc == 0, err[-3000:]
+    line = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(line) == 1, out[-2000:]
+    j = json.loads(line[0])
+    assert j['n_gpus'] == 1 and j['scaling'] == 'weak' and j['value'] > 0
+    assert j['whole_model']['samples_per_s'] > 0 and j['whole_model']['loss_mean'] == j['whole_model']['loss_mean']
+    rc0, out0, err0 = _run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '5', '--warmup', '2', '--batch',
+                            '8192', '--main-only'], timeout=100)
+    assert rc0 == 0, err0[-3000:]
+    j0 = json.loads([l for l in out0.splitlines() if l.startswith('{')][0])
+    assert abs(j['loss_mean'] - j0['loss_mean']) <= 1e-6 * abs(j0['loss_mean'])
