@@ -311,7 +311,9 @@ int vae_nll_fused_grad_finish(void* grecon, const float* gmeans, int64_t n, int 
  * serving loops, harnesses that forbid hipMalloc): the same kernels, with the scratch they need -- the closing
  * launch's arrival counters and block partials, 68 KiB (the first 17408 floats of what a caller's workspace holds;
  * the per-chunk row sums that vae_nll_elbo_fused keeps behind them for long rows are not needed: this entry point
- * runs long rows a block per row) -- in a file-scope __device__ array of the library instead of a caller buffer.  No counterpart in the reference.  The call allocates and frees
+ * runs long rows a block per row: for rows of more than 256 * 4 16-byte vectors its nll / loss / elbo equal the
+ * workspace form's to rounding -- another summation order -- not bit for bit; shorter rows are bit-identical) -- in a
+ * file-scope __device__ array of the library instead of a caller buffer.  No counterpart in the reference.  The call allocates and frees
  * nothing; every GPU the library is used on holds its own copy of the array until the process ends.  Arguments as
  * vae_nll_elbo_fused without `workspace`; the device that owns `stream` must be the current device.  B up to
  * VAE_STATIC_MAX_ROWS, beyond it VAE_ERR_ARG.  All calls on one GPU share that GPU's array: calls that overlap in
