@@ -49,6 +49,23 @@ def test_static_scratch_matches_workspace_entry_point(nll_type, dtype):
             assert torch.equal(r, o), (what, B, D)
 
 
+@pytest.mark.parametrize('nll_type', [0, 2])
+def test_static_scratch_long_rows_to_rounding(nll_type):
+    """Rows of more than 1024 vectors: the workspace form sums a row in chunks (one block per chunk, partial sums in
+    the workspace), this one a block per row -- the gradient bit for bit, nll / loss / elbo and the means to the
+    rounding of another summation order (include/vae_amd.h says so)."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for B, D in ((300, 3 * 64 * 64), (33, 5000)):
+        x = torch.rand(B, D, generator=g, device=DEV)
+        recon = torch.randn(B, D if nll_type == 0 else 2 * D, generator=g, device=DEV)
+        kld = torch.rand(B, generator=g, device=DEV)
+        ref = _run('vae_nll_elbo_fused', x, recon, kld, nll_type, 0, True)
+        got = _run('vae_nll_elbo_fused_static', x, recon, kld, nll_type, 0, False)
+        assert torch.equal(ref[4], got[4])
+        for r, o in zip(ref[:4], got[:4]):
+            torch.testing.assert_close(o, r, rtol=2e-6, atol=0)
+
+
 def test_static_scratch_nan_word():
     """A NaN sample in a multi-block call raises the sticky word of the static scratch (read with workspace = NULL),
     and only there; clearing it works."""
