@@ -8,6 +8,7 @@ sharding + the packed scalar all-reduce).
 from . import _lib  # noqa: F401
 from ._lib import nan_flags  # noqa: F401
 from . import functional  # noqa: F401
+from . import graph  # noqa: F401
 from .reparameterizers import get_reparameterizer, is_module_a_reparameterizer, reparam_dict  # noqa: F401
 from .elbo import ELBOMixin, MSGMixin, AutoencoderMixin, VAENoKLMixin, loss_function, nll, vrnn_loss_function  # noqa: F401
 
