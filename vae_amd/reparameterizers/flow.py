@@ -27,38 +27,32 @@ class FlowReparameterizer(nn.Module):
         elif config.get('flow_builder') is not None:
             self.flow = config['flow_builder'](config)
         else:
-            from .. import flows
-            flow_type, latent_size = config['flow_type'], config['latent_size']
-            if flow_type == 'maf':
-                self.flow = flows.build_maf_flow(num_inputs=continuous_size, num_hidden=latent_size,
-                                                 num_cond_inputs=None, num_blocks=5, activation_str='tanh')
-            elif flow_type == 'maf_split':
-                self.flow = flows.build_maf_split_flow(num_inputs=continuous_size, num_hidden=latent_size,
-                                                       num_cond_inputs=None, num_blocks=5, s_activation_str='tanh',
-                                                       t_activation_str='relu')
-            elif flow_type == 'realnvp':
-                self.flow = flows.build_realnvp_flow(num_inputs=continuous_size, num_hidden=latent_size,
-                                                     num_cond_inputs=None, num_blocks=5, s_activation_str='tanh',
-                                                     t_activation_str='relu',
-                                                     normalization_str=config.get('dense_normalization', 'none'),
-                                                     cuda=config.get('cuda', True))
-            elif flow_type == 'maf_split_glow':
-                self.flow = flows.build_maf_split_glow_flow(num_inputs=continuous_size, num_hidden=latent_size,
-                                                            num_cond_inputs=None, num_blocks=5,
-                                                            s_activation_str='tanh', t_activation_str='relu')
-            elif flow_type == 'glow':
-                self.flow = flows.build_glow_flow(num_inputs=continuous_size, num_hidden=latent_size,
-                                                  num_cond_inputs=None, num_blocks=5,
-                                                  activation_str=config.get('encoder_activation', 'relu'),
-                                                  normalization_str=config.get('dense_normalization', 'none'),
-                                                  layer_modifier=config.get('encoder_layer_modifier', 'none'),
-                                                  cuda=config.get('cuda', True))
-            else:
-                raise ValueError("unknown flow_type '%s'" % (flow_type,))
+            self.flow = self._build(config, continuous_size)
         self.input_size = continuous_size
         self.output_size = continuous_size
         self.inv_count = None    # 1/B_global when sharded
         self.reduce_fn = None    # all-reduce(sum) of one float when sharded (vae_amd.dist)
+
+    @staticmethod
+    def _build(config, features):
+        """The five stacks of flow.py:20-49 (5 blocks each, `latent_size` hidden units), as a table: builder and the
+        keyword arguments that differ from one flow_type to the next."""
+        from .. import flows
+        st = dict(s_activation_str='tanh', t_activation_str='relu')
+        norm = dict(normalization_str=config.get('dense_normalization', 'none'), cuda=config.get('cuda', True))
+        table = {
+            'maf': (flows.build_maf_flow, dict(activation_str='tanh')),
+            'maf_split': (flows.build_maf_split_flow, st),
+            'maf_split_glow': (flows.build_maf_split_glow_flow, st),
+            'realnvp': (flows.build_realnvp_flow, dict(st, **norm)),
+            'glow': (flows.build_glow_flow, dict(norm, activation_str=config.get('encoder_activation', 'relu'),
+                                                 layer_modifier=config.get('encoder_layer_modifier', 'none'))),
+        }
+        kind = config['flow_type']
+        if kind not in table:
+            raise ValueError("unknown flow_type '%s'" % (kind,))
+        builder, extra = table[kind]
+        return builder(num_inputs=features, num_hidden=config['latent_size'], num_cond_inputs=None, num_blocks=5, **extra)
 
     def prior(self, batch_size, scale_var=1.0, **kwargs):
         p = next(self.flow.parameters(), None)
@@ -72,13 +66,15 @@ class FlowReparameterizer(nn.Module):
         return F_.flow_kl(dist_a['recon_x'], dist_a['logdet'], inv_count=self.inv_count, reduce_fn=self.reduce_fn)
 
     def forward(self, logits, force=False):
+        """[B, F] or [B, reads, F] (flow.py:51-65): the flow runs over rows of F features; the logdet comes back as
+        [B, 1] or [B, reads]."""
+        if logits.dim() not in (2, 3):
+            raise ValueError("FlowReparameterizer: logits of %d dimensions" % logits.dim())
+        width = logits.shape[-1]
+        flow, logdet = self.flow(logits.contiguous().view(-1, width))
         if logits.dim() == 3:
-            batch_size, num_reads, input_size = logits.shape
-            flow, logdet = self.flow(logits.contiguous().view(-1, input_size))
-            flow = flow.view([-1, num_reads, input_size])
-            logdet = logdet.view([-1, num_reads])
-        elif logits.dim() == 2:
-            batch_size, input_size = logits.shape
-            flow, logdet = self.flow(logits.contiguous().view(-1, input_size))
-            flow = flow.view([-1, input_size])
+            reads = logits.shape[1]
+            flow, logdet = flow.view(-1, reads, width), logdet.view(-1, reads)
+        else:
+            flow = flow.view(-1, width)
         return flow, {'recon_x': flow, 'logdet': logdet}
