@@ -283,6 +283,38 @@ def test_mixture_constructs_and_runs():
     assert m.kl(params).shape == (16,)
 
 
+@pytest.mark.parametrize('train', [True, False])
+def test_mixture_equals_concat_of_its_children(train):
+    """Mixture(Gaussian, Gumbel) is the pair of the one-launch row kernel: with injected noise its sample, its
+    per-child params and its KL equal the oracle's Concat restatement (the Gaussian part bit for bit), and d(logits)
+    matches."""
+    from vae_amd.reparameterizers import get_reparameterizer
+    torch.manual_seed(12)
+    B, L, K = 257, 64, 32
+    m = get_reparameterizer('mixture')(cfg(continuous_size=2 * L, discrete_size=K)).train(train)
+    logits, noise, U = torch.randn(B, 2 * L + K), torch.randn(B, L), torch.rand(B, K).clamp_(1e-3, 1 - 1e-3)
+    w = torch.randn(B, L + K)
+    lc = logits.clone().requires_grad_(True)
+    z0, p0 = O.concat_forward(lc, [('isotropic_gaussian', 2 * L, {}), ('discrete', K, {'tau': 1.0})],
+                              [noise if train else None, U], training=train)
+    k0 = O.concat_kl(p0, ['isotropic_gaussian', 'discrete'])
+    (g0,) = torch.autograd.grad((z0 * w).sum() + k0.sum(), lc)
+    ld = logits.to(DEV).requires_grad_(True)
+    z1, p1 = m(ld, noise=[noise.to(DEV) if train else None, U.to(DEV)])
+    k1 = m.kl(p1)
+    (g1,) = torch.autograd.grad((z1 * w.to(DEV)).sum() + k1.sum(), ld)
+    assert set(p1) == {'logits', 'z', 'gaussian', 'discrete'} and p1['z'] is z1
+    assert torch.equal(z1[:, :L].cpu(), z0[:, :L].detach())
+    if train:
+        close(z1[:, L:], z0[:, L:], rtol=1e-5, atol=1e-7)
+    else:
+        assert torch.equal(z1[:, L:].cpu() == 1, z0[:, L:] == 1)
+    assert torch.equal(p1['gaussian']['logvar'].cpu(), p0['concat'][0]['gaussian']['logvar'].detach())
+    assert torch.equal(p1['discrete']['z_hard'].cpu() == 1, p0['concat'][1]['discrete']['z_hard'] == 1)
+    close(k1, k0, rtol=1e-5, atol=1e-4)
+    close(g1, g0, rtol=1e-4, atol=1e-5)
+
+
 def test_vrnn_golden(golden):
     from vae_amd import vrnn as V
     from vae_amd.reparameterizers import IsotropicGaussian

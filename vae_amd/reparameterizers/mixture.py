@@ -59,16 +59,25 @@ class Mixture(nn.Module):
         return torch.cat([cont, disc], 1)
 
     def forward(self, logits, force=False, noise=None):
-        noise = [None, None] if noise is None else noise
+        """`noise`: optional [continuous noise, Gumbel uniforms] (each may be None).  Gaussian + Gumbel on 2-D logits
+        is the pair of csrc/concat.hip: ONE launch over the [2L + K] row, the sample written contiguously; a Beta
+        continuous part (its sample is ATen's) or other ranks take the two children's own launches."""
+        noise = [None, None] if noise is None else list(noise)
+        key = 'beta' if self.is_beta else 'gaussian'
+        if not self.is_beta and logits.dim() == 2:
+            from .concat_reparameterizer import fused_forward
+            merged, p = fused_forward([self.continuous, self.discrete], logits, bool(self.training or force), noise)
+            cont, disc = p['concat']
+            return merged, {'logits': logits, 'z': merged, key: cont[key], 'discrete': disc['discrete']}
         n_c = self.num_continuous_input
-        kw = {} if noise[0] is None else {'noise': noise[0]}
-        continuous, continuous_params = self.continuous(logits[:, 0:n_c], force=force, **kw)
-        kw = {} if noise[1] is None else {'noise': noise[1]}
-        discrete, disc_params = self.discrete(logits[:, n_c:], force=force, **kw)
-        merged = torch.cat([continuous, discrete], -1)
-        key = 'gaussian' if not self.is_beta else 'beta'
-        params = {'logits': logits, 'z': merged, key: continuous_params[key], 'discrete': disc_params['discrete']}
-        return merged, params
+        parts, params = [], {'logits': logits}
+        for child, sl, n, k in ((self.continuous, slice(0, n_c), noise[0], key),
+                                (self.discrete, slice(n_c, None), noise[1], 'discrete')):
+            z_i, p_i = child(logits[:, sl], force=force, **({} if n is None else {'noise': n}))
+            parts.append(z_i)
+            params[k] = p_i[k]
+        params['z'] = torch.cat(parts, -1)
+        return params['z'], params
 
     def reparmeterize(self, logits, force=False, noise=None):
         # mixture.py:91-107 (the reference class defines no forward(); nn.Module callers go through this)
