@@ -269,22 +269,35 @@ __global__ __launch_bounds__(kBlock) void elbo_rows_means_kernel(const T* __rest
   }
   double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   const int64_t nvec = B / V;   // whole vectors; the B % V rows of the tail go to the first threads of block 0
-  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < nvec; j += (int64_t)gridDim.x * kBlock) {
-    float a[6][V];
-    load_vec<T, V, false>(loss + j * V, a[0]);
-    load_vec<T, V, false>(elbo + j * V, a[1]);
-    load_vec<T, V, false>(nll + j * V, a[2]);
-    if (kld) load_vec<T, V, false>(kld + j * V, a[3]);
-    if (add) load_vec<T, V, false>(add + j * V, a[4]);
-    if (mi) load_vec<T, V, false>(mi + j * V, a[5]);
+  // kAhead of a thread's vectors are requested before the first is added (the single-block form of small batches walks
+  // up to 8 per array: one memory round trip per vector otherwise); the additions stay in j order
+  constexpr int kAhead = 4;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t j0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; j0 < nvec; j0 += stride * kAhead) {
+    float a[kAhead][6][V];
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-      v[0] += (double)a[0][i];
-      v[1] += (double)a[1][i];
-      v[2] += (double)a[2][i];
-      if (kld) v[3] += (double)a[3][i];
-      if (add) v[4] += (double)a[4][i];
-      if (mi) v[5] += (double)a[5][i];
+    for (int u = 0; u < kAhead; ++u) {
+      const int64_t j = j0 + u * stride < nvec ? j0 + u * stride : j0;
+      load_vec<T, V, false>(loss + j * V, a[u][0]);
+      load_vec<T, V, false>(elbo + j * V, a[u][1]);
+      load_vec<T, V, false>(nll + j * V, a[u][2]);
+      if (kld) load_vec<T, V, false>(kld + j * V, a[u][3]);
+      if (add) load_vec<T, V, false>(add + j * V, a[u][4]);
+      if (mi) load_vec<T, V, false>(mi + j * V, a[u][5]);
+    }
+#pragma unroll
+    for (int u = 0; u < kAhead; ++u) {
+      if (j0 + u * stride < nvec) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          v[0] += (double)a[u][0][i];
+          v[1] += (double)a[u][1][i];
+          v[2] += (double)a[u][2][i];
+          if (kld) v[3] += (double)a[u][3][i];
+          if (add) v[4] += (double)a[u][4][i];
+          if (mi) v[5] += (double)a[u][5][i];
+        }
+      }
     }
   }
   if (blockIdx.x == 0 && (int64_t)threadIdx.x < B - nvec * V) {
