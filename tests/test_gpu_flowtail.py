@@ -427,3 +427,28 @@ def test_flow_sequential_pairs_made_with_batchnorm(monkeypatch):
     seen.clear()
     net(x)
     assert not any(seen)
+
+
+@pytest.mark.parametrize('half', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('Fd', [2048, 4096, 9008])
+def test_bnflow_16bit_wide_rows(half, Fd):
+    """16-bit BatchNormFlow on rows of 256..1126 eight-element vectors: the column moments are taken in windows of
+    two vectors per lane (four 8-element vectors per lane do not fit the register file), forward and backward."""
+    from vae_amd import functional as F_
+    torch.manual_seed(Fd)
+    B = 260
+    x = (torch.randn(B, Fd) * (0.5 + torch.rand(Fd)) + torch.randn(Fd)).to(half)
+    lg, beta = torch.randn(Fd) * 0.2, torch.randn(Fd)
+    w = torch.randn(B, Fd)
+    xc, lgc, bc = x.float().requires_grad_(True), lg.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y0, ld0, mean0, var0 = O.bnflow(xc, lgc, bc, None, None, training=True)
+    g0 = torch.autograd.grad((y0 * w).sum(), [xc, lgc, bc])
+    xd, lgd, bd = x.to(DEV).requires_grad_(True), lg.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    y1, ld1, mean1, var1 = F_.bnflow(xd, lgd, bd, training=True)
+    g1 = torch.autograd.grad((y1.float() * w.to(DEV)).sum(), [xd, lgd, bd])
+    close(mean1, mean0, rtol=1e-4, atol=1e-4)
+    close(var1, var0, rtol=1e-3, atol=1e-5)
+    close(y1, y0, rtol=2e-2, atol=2e-2)
+    close(g1[1], g0[1], rtol=3e-2, atol=0.5)
+    close(g1[2], g0[2], rtol=3e-2, atol=0.5)
+    close(g1[0], g0[0], rtol=5e-2, atol=5e-2 * float(g0[0].abs().max()))

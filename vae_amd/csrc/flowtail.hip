@@ -711,17 +711,24 @@ static void bn_colstats_launch(int NJ, int grid, hipStream_t st, const T* x, con
                                const float* rstd, float* part, int64_t B, int F, int mode, int rev, int G,
                                int64_t tiles) {
   const int nvec = F / V;
+  // row tiles in flight: 8 column-vectors of loads per lane and tensor for 4-element vectors, 4 for the 8-element
+  // vectors of the 16-bit types (their registers hold twice the floats: NJ * R = 8 spilled 64-112 bytes per lane to
+  // scratch there, -Rpass-analysis=kernel-resource-usage, r03)
+  constexpr int R2 = V >= 8 ? 2 : 4;
+  // four 8-element vectors per lane do not fit either (the compiler pairs the 32 shift constants for packed
+  // arithmetic and parks them in scratch): wide 16-bit rows take windows of two vectors per lane instead
+  constexpr int NJW = V >= 8 ? 2 : 4;
   if (NJ == 1)
     hipLaunchKernelGGL((bn_colstats_kernel<T, V, 1, 4>), dim3(grid), dim3(kBlock), 0, st, x, gy, gld, mean, rstd, part,
                        B, F, mode, rev, G, tiles, 0, nvec);
   else if (NJ == 2)
-    hipLaunchKernelGGL((bn_colstats_kernel<T, V, 2, 4>), dim3(grid), dim3(kBlock), 0, st, x, gy, gld, mean, rstd, part,
+    hipLaunchKernelGGL((bn_colstats_kernel<T, V, 2, R2>), dim3(grid), dim3(kBlock), 0, st, x, gy, gld, mean, rstd, part,
                        B, F, mode, rev, G, tiles, 0, nvec);
   else
-    for (int j0 = 0; j0 < nvec; j0 += G * kBnChunks) {   // one window unless the row is wider than kBlock * kBnChunks vectors
-      const int w = nvec - j0 < G * kBnChunks ? nvec - j0 : G * kBnChunks;
-      hipLaunchKernelGGL((bn_colstats_kernel<T, V, 4, 2>), dim3(grid), dim3(kBlock), 0, st, x, gy, gld, mean, rstd, part,
-                         B, F, mode, rev, G, tiles, j0, w);
+    for (int j0 = 0; j0 < nvec; j0 += G * NJW) {   // one window unless the row is wider than G * NJW vectors
+      const int w = nvec - j0 < G * NJW ? nvec - j0 : G * NJW;
+      hipLaunchKernelGGL((bn_colstats_kernel<T, V, NJW, (V >= 8 ? R2 : 2)>), dim3(grid), dim3(kBlock), 0, st, x, gy, gld,
+                         mean, rstd, part, B, F, mode, rev, G, tiles, j0, w);
     }
 }
 
