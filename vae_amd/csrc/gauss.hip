@@ -103,8 +103,11 @@ __global__ __launch_bounds__(kBlock) void gauss_fwd_kernel(
 // ---------------------------------------------------------------------------
 // backward: d logits from d z, d logvar, d kl and the two mean diagnostics
 // ---------------------------------------------------------------------------
+// At least four waves per SIMD for the one- and two-chunk forms: the 16-bit two-chunk instantiation otherwise takes
+// 130 registers -- two over the 128 of occupancy 4 -- and runs at occupancy 3 (bf16 L=512: 70.5 -> 67.6 us with the
+// bound, 12 bytes per lane of spill; five waves spill 156 bytes and halve the throughput: scripts/ab.py, r03).
 template <typename T, int V, int U>
-__global__ __launch_bounds__(kBlock) void gauss_bwd_kernel(
+__global__ __launch_bounds__(kBlock, (U <= 2 ? 4 : 1)) void gauss_bwd_kernel(
     const T* __restrict__ logits, int64_t row_stride, const T* __restrict__ noise, const T* __restrict__ gz,
     int64_t gz_stride, const T* __restrict__ gs, const T* __restrict__ gkl, const float* __restrict__ gmeans,
     T* __restrict__ glogits, int64_t gl_stride, int64_t B, int L, float eps_tol, float mean_scale, int training, uint64_t seed, uint64_t offset, int64_t row0,
