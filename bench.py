@@ -38,6 +38,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from vae_amd.timing import Event as _Event  # noqa: E402  (HIP events without a system-scope fence)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 B_PER_GPU, L, C, H, W = 65536, 512, 1, 28, 28
@@ -272,7 +273,7 @@ def main():
     # timed regions and kept out of `value` (an event record is a barrier packet: bracketing all four launches costs
     # ~15 us of a 326 us step).  BENCH_EVENT_EVERY=n brackets every n-th step of that region only.
     every = max(1, int(os.environ.get('BENCH_EVENT_EVERY', '1')))
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] if k % every == 0 else None
+    events = [[_Event() for _ in range(6)] if k % every == 0 else None
               for k in range(args.steps)]
 
     def fence():
@@ -347,7 +348,7 @@ def main():
         noise_arg[0] = None
         for _ in range(args.warmup):
             step()
-        ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] if k % every == 0 else None
+        ev2 = [[_Event() for _ in range(6)] if k % every == 0 else None
                for k in range(args.steps)]
         for k in range(args.steps):
             step(ev2[k])
@@ -380,7 +381,7 @@ def main():
         noise_arg[0] = ptr(T['noise'])
         for _ in range(args.warmup):
             step()
-        ev3 = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
+        ev3 = [[_Event() for _ in range(6)] for _ in range(args.steps)]
         for k in range(args.steps):
             step(ev3[k])
         torch.cuda.synchronize(dev)
@@ -454,7 +455,7 @@ def main():
             rc.grad = None
         for _ in range(5):
             mstep()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = _Event(), _Event()
         torch.cuda.synchronize(dev)
         e0.record()
         for _ in range(20):
@@ -708,7 +709,7 @@ def stock_torch_step_rate(logits, noise, x, recon, gz, steps=10):
         return out
     for _ in range(3):
         one()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0, e1 = _Event(), _Event()
     torch.cuda.synchronize()
     e0.record()
     for _ in range(steps):

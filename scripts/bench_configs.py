@@ -19,6 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vae_amd import _lib
 from vae_amd._lib import call, ptr
+from vae_amd.timing import Event
 
 dev = torch.device('cuda', 0)
 ws = _lib.workspace(dev)
@@ -43,7 +44,8 @@ def timeit(name, cfg, fn, nbytes, iters=20):
     global _flush
     for _ in range(5):
         fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # events without a system-scope fence (vae_amd/timing.py): ~2 us closer to rocprofv3's kernel durations
+    e0, e1 = Event(), Event()
     torch.cuda.synchronize()
     if nbytes >= (32 << 20) and not LOOP:
         if _flush is None:
