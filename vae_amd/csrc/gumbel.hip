@@ -424,6 +424,19 @@ __global__ __launch_bounds__(kBlock) void categorical_kl_long_kernel(
 
 constexpr int kLongRowGrid = 8192;   // blocks of a long-row launch (one row each, grid-strided beyond)
 
+// The sampling kernels hold more per chunk than the KL does (noise, the soft sample, the hard mask): four chunks per
+// lane cost them occupancy 4 (97-125 registers in fp32, 138-190 in the 16-bit types).  Two chunks on twice the lanes
+// measured better wherever a 64-lane group still holds the row (r03, cold-cache, B = 65536: K = 256 all-output forward
+// 49.9 -> 47.7 us with in-kernel noise, 61.4 -> 58.5 injected, backward 36.9 -> 35.2; K = 512 forward 100.2 -> 90.5 /
+// 117.5 -> 113.3; K = 128 33.6 -> 31.7); the categorical KL keeps four (43.0 vs 44.6 us at K = 512).
+static void gumbel_regroup(RowGeom& g, int64_t rows, int64_t vecs) {
+  if (knobs().G || knobs().U || g.G >= 64 || g.U != 4) return;
+  int G = g.G;
+  while (G < 64 && (vecs + G - 1) / G > 2) G <<= 1;
+  if ((vecs + G - 1) / G > 2) return;
+  regroup(g, rows, G, (vecs + G - 1) / G >= 2 ? 2 : 1, kGridStream);
+}
+
 template <typename T>
 static int gumbel_fwd_dispatch(const void* logits, int64_t row_stride, const void* unif, void* y, int64_t ys, void* zh,
                                int64_t zs, void* lq,
@@ -444,6 +457,7 @@ static int gumbel_fwd_dispatch(const void* logits, int64_t row_stride, const voi
                          row_stride, (const T*)unif, (T*)y, ys, (T*)zh, zs, (T*)lq, B, (int)K, tau, seed, offset, row0);
     return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
   }
+  if (vec) gumbel_regroup(g, B, K / VN);
 #define VAE_GUMBEL_FWD(VV, INJ_)                                                                                   \
   VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gumbel_fwd_kernel<T, VV, U, INJ_>), dim3(g.grid), dim3(kBlock), 0, stream,     \
                                        (const T*)logits, row_stride, (const T*)unif, (T*)y, ys, (T*)zh, zs, (T*)lq, B, \
@@ -477,6 +491,7 @@ static int gumbel_bwd_dispatch(const void* y, int64_t ys, const void* lq, const 
                          tau);
     return hipGetLastError() == hipSuccess ? VAE_OK : VAE_ERR_LAUNCH;
   }
+  if (vec) gumbel_regroup(g, B, K / VN);
   if (vec) {
     VAE_SWITCH_U(g.U, hipLaunchKernelGGL((gumbel_bwd_kernel<T, VN, U>), dim3(g.grid), dim3(kBlock), 0, stream,
                                          (const T*)y, ys, (const T*)lq, (const T*)gy, gys, (const T*)gzh, gzs,
