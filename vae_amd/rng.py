@@ -70,8 +70,10 @@ def next_calls(n):
     if seed != _state['seed']:
         _state['seed'] = seed
         _state['offset'] = 0
-    if torch.cuda.is_available():
-        _pool(torch.device('cuda', torch.cuda.current_device()), create=True)   # outside any capture
+    if not _pools and torch.cuda.is_available():
+        # outside any capture; once per process (one process per GPU): a second device used by the same process falls
+        # back to words from its graph's own pool (_captured_offset)
+        _pool(torch.device('cuda', torch.cuda.current_device()), create=True)
     first = _state['offset'] + 1
     _state['offset'] += n
     return seed, first
