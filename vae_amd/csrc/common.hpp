@@ -288,17 +288,40 @@ __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
 }
 
+// The 16- and 32-lane levels of the butterfly: gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd 16-lane
+// rows of one register with the even rows of another (the upper and lower 32 lanes for the second), at VALU speed.
+// Called with two copies of v, the first register comes back holding the even-row (lower-half) values in both rows
+// of every pair and the second the odd-row (upper-half) values: their sum / max IS the xor-16 / xor-32 butterfly step,
+// the same bits in both partners -- where ds_bpermute (__shfl_xor) is an LDS round trip of ~120 cycles behind an
+// lgkmcnt wait.  Inline asm: the builtin's two results are mis-selected by hipcc 7.2 (both read the first register:
+// scripts/exp/permlane_test.hip checks this form against __shfl_xor on the GPU); the s_nop is the wait state the
+// instruction needs behind the VALU writes of its operands, which the compiler cannot see here.
+#ifndef VAE_NO_PERMLANE_SWAP
+__device__ __forceinline__ void swap16(float v, float& a, float& b) {
+  a = v; b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap32(float v, float& a, float& b) {
+  a = v; b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+#else
+__device__ __forceinline__ void swap16(float v, float& a, float& b) { a = v; b = __shfl_xor(v, 16, 64); }
+__device__ __forceinline__ void swap32(float v, float& a, float& b) { a = v; b = __shfl_xor(v, 32, 64); }
+#endif
+
 // Sum / max over the G lanes that share a row (G power of two, <= 64; every lane of the wave takes part: the call
 // sites are in block-uniform control flow).  Butterfly: xor 1 and xor 2 inside the quads, then the half-row and row
-// mirrors (the sub-groups they pair already hold equal values) by DPP; the 16- and 32-lane levels by ds_bpermute.
+// mirrors (the sub-groups they pair already hold equal values) by DPP; the 16- and 32-lane levels by permlane swaps.
 // After it every lane of the group holds the result, the same bits in all of them.
 __device__ __forceinline__ float group_sum(float v, int G) {
   if (G >= 2) v += dpp_f<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
   if (G >= 4) v += dpp_f<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
   if (G >= 8) v += dpp_f<0x141, 0xf>(v);   // row_half_mirror
   if (G >= 16) v += dpp_f<0x140, 0xf>(v);  // row_mirror
-  if (G >= 32) v += __shfl_xor(v, 16, 64);
-  if (G >= 64) v += __shfl_xor(v, 32, 64);
+  float a, b;
+  if (G >= 32) { swap16(v, a, b); v = a + b; }
+  if (G >= 64) { swap32(v, a, b); v = a + b; }
   return v;
 }
 __device__ __forceinline__ float group_max(float v, int G) {
@@ -306,8 +329,9 @@ __device__ __forceinline__ float group_max(float v, int G) {
   if (G >= 4) v = fmaxf(v, dpp_f<0x4E, 0xf>(v));
   if (G >= 8) v = fmaxf(v, dpp_f<0x141, 0xf>(v));
   if (G >= 16) v = fmaxf(v, dpp_f<0x140, 0xf>(v));
-  if (G >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
-  if (G >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
+  float a, b;
+  if (G >= 32) { swap16(v, a, b); v = fmaxf(a, b); }
+  if (G >= 64) { swap32(v, a, b); v = fmaxf(a, b); }
   return v;
 }
 __device__ __forceinline__ float wave_sum(float v) { return group_sum(v, 64); }
