@@ -324,14 +324,22 @@ __device__ __forceinline__ float group_sum(float v, int G) {
   if (G >= 64) { swap32(v, a, b); v = a + b; }
   return v;
 }
+// max(a, b) as the bare instruction.  fmaxf() costs three: the compiler quiets both operands first (v_max_f32 x, x)
+// because IEEE maxNum must not return a signalling NaN -- which v_max_f32 in the IEEE mode these kernels run in does
+// not do either.  Same result as fmaxf for every input, a NaN operand included (the other one is returned).
+__device__ __forceinline__ float max_raw(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ float group_max(float v, int G) {
-  if (G >= 2) v = fmaxf(v, dpp_f<0xB1, 0xf>(v));
-  if (G >= 4) v = fmaxf(v, dpp_f<0x4E, 0xf>(v));
-  if (G >= 8) v = fmaxf(v, dpp_f<0x141, 0xf>(v));
-  if (G >= 16) v = fmaxf(v, dpp_f<0x140, 0xf>(v));
+  if (G >= 2) v = max_raw(v, dpp_f<0xB1, 0xf>(v));
+  if (G >= 4) v = max_raw(v, dpp_f<0x4E, 0xf>(v));
+  if (G >= 8) v = max_raw(v, dpp_f<0x141, 0xf>(v));
+  if (G >= 16) v = max_raw(v, dpp_f<0x140, 0xf>(v));
   float a, b;
-  if (G >= 32) { swap16(v, a, b); v = fmaxf(a, b); }
-  if (G >= 64) { swap32(v, a, b); v = fmaxf(a, b); }
+  if (G >= 32) { swap16(v, a, b); v = max_raw(a, b); }
+  if (G >= 64) { swap32(v, a, b); v = max_raw(a, b); }
   return v;
 }
 __device__ __forceinline__ float wave_sum(float v) { return group_sum(v, 64); }

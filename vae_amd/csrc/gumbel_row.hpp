@@ -36,7 +36,7 @@ __device__ __forceinline__ void gumbel_row_fwd(const float (&l)[U][V], float (&u
 #pragma unroll
     for (int k = 0; k < U; ++k)
 #pragma unroll
-      for (int i = 0; i < V; ++i) m1 = fmaxf(m1, valid[k] ? l[k][i] : kNegInf);
+      for (int i = 0; i < V; ++i) m1 = max_raw(m1, valid[k] ? l[k][i] : kNegInf);
     m1 = row_max(m1, G);
     float s1 = 0.f;
 #pragma unroll
@@ -78,7 +78,7 @@ __device__ __forceinline__ void gumbel_row_fwd(const float (&l)[U][V], float (&u
         g = to_f32(from_f32<T>(g));
         const float xi = to_f32(from_f32<T>(div_rn(to_f32(from_f32<T>(add_rn(l[k][i], g))), tau)));
         x[k][i] = to_f32(from_f32<T>(add_rn(xi, kGumbelEps)));
-        m2 = fmaxf(m2, valid[k] ? x[k][i] : kNegInf);
+        m2 = max_raw(m2, valid[k] ? x[k][i] : kNegInf);
       }
     }
     m2 = row_max(m2, G);
@@ -109,7 +109,7 @@ __device__ __forceinline__ void gumbel_row_fwd(const float (&l)[U][V], float (&u
         const float ue = __builtin_fmaf((float)(w[i] >> 8), 1.0f / 16777216.0f, 0.5f / 16777216.0f + kGumbelEps);
         const float g1 = __builtin_fmaf(-kLn2, log2_raw(ue), kGumbelEps);
         x[k][i] = __builtin_fmaf(log2_raw(g1), c2, __builtin_fmaf(l[k][i], c, c0));
-        m2 = fmaxf(m2, valid[k] ? x[k][i] : kNegInf);
+        m2 = max_raw(m2, valid[k] ? x[k][i] : kNegInf);
       }
     }
     m2 = row_max(m2, G);
@@ -129,7 +129,7 @@ __device__ __forceinline__ void gumbel_row_fwd(const float (&l)[U][V], float (&u
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       x[k][i] = to_f32(from_f32<T>(mul_rn(x[k][i], rinv)));
-      ymax = fmaxf(ymax, valid[k] ? x[k][i] : 0.f);
+      ymax = max_raw(ymax, valid[k] ? x[k][i] : 0.f);
     }
   // the largest y needs no reduction when z_hard is not wanted
   if (zh) ymax = row_max(ymax, G);
