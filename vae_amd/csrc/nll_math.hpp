@@ -214,7 +214,7 @@ inline RowGeom nll_geom(int64_t B, int64_t vecs_per_row, int64_t max_grid, bool 
 // loads -- is 8-10 dependent round trips of ~1 us on a loaded chip; a static partition loses ~7 us to the dynamic
 // hand-out whatever its grid: scripts/membench.hip).  Thread i adds vectors i, i + grid*256, ... in order (double);
 // blocks in block order: deterministic for a given B.
-template <typename T, int V>
+template <typename T, int V, int kAhead = 4>
 __global__ __launch_bounds__(kBlock) void elbo_rows_means_kernel(const T* __restrict__ loss, const T* __restrict__ elbo,
                                                                  const T* __restrict__ nll, const T* __restrict__ kld,
                                                                  const T* __restrict__ add, const T* __restrict__ mi,
@@ -271,7 +271,6 @@ __global__ __launch_bounds__(kBlock) void elbo_rows_means_kernel(const T* __rest
   const int64_t nvec = B / V;   // whole vectors; the B % V rows of the tail go to the first threads of block 0
   // kAhead of a thread's vectors are requested before the first is added (the single-block form of small batches walks
   // up to 8 per array: one memory round trip per vector otherwise); the additions stay in j order
-  constexpr int kAhead = 4;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t j0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; j0 < nvec; j0 += stride * kAhead) {
     float a[kAhead][6][V];
@@ -324,7 +323,11 @@ inline void launch_rows_means(const void* loss, const void* elbo, const void* nl
   int64_t blocks = (items + kBlock - 1) / kBlock;
   // small batches: ONE block (<= 8 vectors per thread and array) closes without the cross-block ticket chain
   const int grid = items <= 8 * kBlock ? 1 : (int)(blocks < 64 ? blocks : 64);
-  if (vec)
+  if (vec && grid > 1 && blocks <= 64)   // one vector per thread: nothing to request ahead
+    hipLaunchKernelGGL((elbo_rows_means_kernel<T, VN, 1>), dim3(grid), dim3(kBlock), 0, stream, (const T*)loss,
+                       (const T*)elbo, (const T*)nll, (const T*)kld, (const T*)add, (const T*)mi, ws, inv_count, means, B,
+                       steps, (T*)loss_avg, (T*)elbo_avg, (T*)elbo_lse);
+  else if (vec)
     hipLaunchKernelGGL((elbo_rows_means_kernel<T, VN>), dim3(grid), dim3(kBlock), 0, stream, (const T*)loss, (const T*)elbo,
                        (const T*)nll, (const T*)kld, (const T*)add, (const T*)mi, ws, inv_count, means, B, steps,
                        (T*)loss_avg, (T*)elbo_avg, (T*)elbo_lse);
